@@ -1,0 +1,32 @@
+"""Explicit configuration for the PoseNet inference path.
+
+The reference reads a global absl ``FLAGS`` singleton inside module constructors
+(config/config.py:5-128; read sites: network/PoseNet.py:138-171,
+network/conv_pnp_net.py:121,254, network/pose_head.py:22).  This dataclass carries
+the ~12 flags the inference path reads, with the reference's defaults.
+"""
+from dataclasses import dataclass, field
+from typing import Tuple
+
+
+@dataclass(frozen=True)
+class PoseNetConfig:
+    main_backbone: str = "convnext"      # config.py:113 ('convnext' | 'resnet34' throughput variant)
+    img_size: int = 256                  # config.py:20
+    out_res: int = 64                    # config.py:21
+    mask_attention_type: str = "none"    # config.py:22
+    feat_ts: int = 128                   # config.py:39
+    flat_op: str = "flatten"             # config.py:105
+    t_type: str = "site"                 # config.py:108
+    size_head_out_dim: int = 3           # config.py:109
+    nocsmap_encoder: str = "conv"        # config.py:111 ('conv' | 'att')
+    r_type: str = "allo_rot6d"           # config.py:116
+    use_dcn: str = "dcnv3"               # config.py:120 ('dcnv3' | '')
+    dataset: str = "CAMERA+Real"         # config.py:9 ('wild6d' rescales z, pose_from_pred_centroid_z.py:110)
+    # ConvNeXt-Base (timm convnext_base, network/backbone.py:36-46)
+    convnext_dims: Tuple[int, ...] = (128, 256, 512, 1024)
+    convnext_depths: Tuple[int, ...] = (3, 3, 27, 3)
+
+    @property
+    def feature_channel(self) -> int:
+        return {"convnext": self.convnext_dims[-1], "resnet34": 512}[self.main_backbone]
