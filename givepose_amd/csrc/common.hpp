@@ -1,0 +1,87 @@
+// Shared helpers for the givepose_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/givepose_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------- errors
+extern thread_local char gp_err_buf[512];
+int gp_fail(int code, const char* fmt, ...);
+
+#define GP_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return gp_fail(GP_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define GP_LAUNCH_CHECK(name)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) return gp_fail(GP_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+        return gp_timing_after(name);                                                      \
+    } while (0)
+
+// per-launch timing hooks (bench.py's roofline leg); no-ops unless gp_timing_begin() was called
+void gp_timing_before(hipStream_t s, int cls, double flops, double bytes);
+int gp_timing_after(const char* name);
+
+// ---------------------------------------------------------------------------------- vectors
+// One 16-byte vector of T: 8 halfs or 4 floats.
+template <typename T> struct Vec16;
+template <> struct Vec16<half_t> {
+    static constexpr int N = 8;
+    union { uint4 u; half_t e[8]; };
+    __device__ __forceinline__ float get(int i) const { return (float)e[i]; }
+    __device__ __forceinline__ void set(int i, float v) { e[i] = (half_t)v; }
+};
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    union { uint4 u; float e[4]; };
+    __device__ __forceinline__ float get(int i) const { return e[i]; }
+    __device__ __forceinline__ void set(int i, float v) { e[i] = v; }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+    Vec16<T> v;
+    v.u = *reinterpret_cast<const uint4*>(p);
+    return v;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
+    *reinterpret_cast<uint4*>(p) = v.u;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+    Vec16<T> v;
+    v.u = make_uint4(0, 0, 0, 0);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case GP_ACT_GELU: return gelu_erf(v);
+        case GP_ACT_RELU: return fmaxf(v, 0.0f);
+        case GP_ACT_LRELU: return v > 0.0f ? v : 0.1f * v;
+        default: return v;
+    }
+}
+
+// sum over the `width` (power of two, <= 64) consecutive lanes that contain this lane
+__device__ __forceinline__ float group_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group_max(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

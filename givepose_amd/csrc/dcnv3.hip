@@ -1,0 +1,219 @@
+// DCNv3 forward (deformable bilinear gather) for gfx950.
+//
+// Follows the arithmetic of the reference CUDA kernel
+//   network/ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh:216-282 (+ :32-80 bilinear)
+// -- same flat offset/mask addressing, tap order (kernel_w outer, kernel_h inner), bounds test,
+// zero padding and fp32 accumulation -- but not its thread mapping (one thread per output scalar,
+// every one of the D channel threads re-reading the same 27 offset/mask scalars).
+//
+// Two kernels:
+//  * dcnv3_wave_kernel (G*D == 256, D == 64, K*K-rc <= 16: the PoseNet geometry): one wavefront
+//    per output pixel, 16 lanes per group, 4 channels per lane.  Lane t < P of each 16-lane row
+//    loads tap t's (offset_w, offset_h, mask) once; the softmax over the taps (when the caller hands
+//    over mask logits) is a 16-lane butterfly; per tap the three scalars are broadcast inside the
+//    row with wave shuffles (no memory traffic) and every corner fetch is one fully coalesced
+//    128-B (f16) / 256-B (f32) row segment per group.
+//  * dcnv3_generic_kernel: any G, D % 4 == 0, any K: one thread per (pixel, group, 4 channels).
+#include "common.hpp"
+
+namespace {
+
+struct DcnKP {
+    const void* in;
+    const void* off;
+    const void* mask;
+    void* out;
+    int N, H, W, G, D, K, stride, pad, dil, rc, Ho, Wo, off_ld, mask_ld, logits;
+    float os;
+    long rows;  // N*Ho*Wo
+};
+
+template <typename T> struct Ch4;  // 4 channels of T
+template <> struct Ch4<half_t> {
+    half4 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct Ch4<float> {
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+};
+template <typename T> __device__ __forceinline__ Ch4<T> ld4(const T* p) {
+    Ch4<T> c;
+    c.v = *reinterpret_cast<const decltype(c.v)*>(p);
+    return c;
+}
+__device__ __forceinline__ void st4(half_t* p, const float* a) {
+    half4 v;
+    for (int i = 0; i < 4; ++i) v[i] = (half_t)a[i];
+    *reinterpret_cast<half4*>(p) = v;
+}
+__device__ __forceinline__ void st4(float* p, const float* a) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a[0], a[1], a[2], a[3]};
+}
+
+// bilinear sample of 4 channels at (h, w) with zero padding; `im` points at channel 0 of this
+// lane's 4 channels of pixel (0,0) of image b; cstride = G*D
+template <typename T>
+__device__ __forceinline__ void bilinear4(const T* im, int H, int W, int cstride, float h, float w, float wgt,
+                                          float* acc) {
+    const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h - h_low, lw = w - w_low, hh = 1.f - lh, hw = 1.f - lw;
+    const bool hl = h_low >= 0, hhi = h_high <= H - 1, wl = w_low >= 0, whi = w_high <= W - 1;
+    const long rs = (long)W * cstride;
+    const T* p1 = im + h_low * rs + (long)w_low * cstride;
+    Ch4<T> v1, v2, v3, v4;
+    const bool o1 = hl && wl, o2 = hl && whi, o3 = hhi && wl, o4 = hhi && whi;
+    if (o1) v1 = ld4(p1);
+    if (o2) v2 = ld4(p1 + cstride);
+    if (o3) v3 = ld4(p1 + rs);
+    if (o4) v4 = ld4(p1 + rs + cstride);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a = o1 ? v1.get(c) : 0.f, b = o2 ? v2.get(c) : 0.f, d = o3 ? v3.get(c) : 0.f,
+                    e = o4 ? v4.get(c) : 0.f;
+        acc[c] += (w1 * a + w2 * b + w3 * d + w4 * e) * wgt;
+    }
+}
+
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
+    const int DV = p.D >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.rows * p.G * DV) return;
+    const int cv = (int)(idx % DV);
+    long t = idx / DV;
+    const int g = (int)(t % p.G);
+    const long r = t / p.G;
+    const int wo = (int)(r % p.Wo);
+    const long t2 = r / p.Wo;
+    const int ho = (int)(t2 % p.Ho);
+    const int b = (int)(t2 / p.Ho);
+    const int P = p.K * p.K - p.rc;
+    const OT* op = reinterpret_cast<const OT*>(p.off) + r * p.off_ld + g * P * 2;
+    const OT* mp = reinterpret_cast<const OT*>(p.mask) + r * p.mask_ld + g * P;
+    float mmax = 0.f, minv = 1.f;
+    if (p.logits) {
+        mmax = -INFINITY;
+        for (int q = 0; q < P; ++q) mmax = fmaxf(mmax, (float)mp[q]);
+        float s = 0.f;
+        for (int q = 0; q < P; ++q) s += expf((float)mp[q] - mmax);
+        minv = 1.f / s;
+    }
+    const int halfk = (p.dil * (p.K - 1)) >> 1;
+    const float p0_w_ = (float)(halfk - p.pad + wo * p.stride) - halfk * p.os;
+    const float p0_h_ = (float)(halfk - p.pad + ho * p.stride) - halfk * p.os;
+    const int cs = p.G * p.D;
+    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * cs + g * p.D + cv * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (int i = 0; i < p.K; ++i)
+        for (int j = 0; j < p.K; ++j) {
+            if (p.rc && i == p.K / 2 && j == p.K / 2) continue;
+            const float ow = (float)op[2 * q], oh = (float)op[2 * q + 1];
+            const float loc_w = p0_w_ + (i * p.dil + ow) * p.os;
+            const float loc_h = p0_h_ + (j * p.dil + oh) * p.os;
+            float wgt = (float)mp[q];
+            if (p.logits) wgt = expf(wgt - mmax) * minv;
+            if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)p.H && loc_w < (float)p.W)
+                bilinear4<T>(im, p.H, p.W, cs, loc_h, loc_w, wgt, acc);
+            ++q;
+        }
+    st4(reinterpret_cast<T*>(p.out) + r * cs + g * p.D + cv * 4, acc);
+}
+
+// One wavefront per output pixel; G == 4, D == 64 (lane = g*16 + cv), P <= 16.
+template <typename T, typename OT>
+__global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.rows) return;  // whole wave exits together
+    const int g = lane >> 4, t = lane & 15;
+    const int wo = (int)(r % p.Wo);
+    const long t2 = r / p.Wo;
+    const int ho = (int)(t2 % p.Ho);
+    const int b = (int)(t2 / p.Ho);
+    const int P = p.K * p.K - p.rc;
+    // lane t < P of row g owns tap t
+    float ow = 0.f, oh = 0.f, mk = p.logits ? -INFINITY : 0.f;
+    if (t < P) {
+        const OT* op = reinterpret_cast<const OT*>(p.off) + r * p.off_ld + (g * P + t) * 2;
+        ow = (float)op[0];
+        oh = (float)op[1];
+        mk = (float)(reinterpret_cast<const OT*>(p.mask)[r * p.mask_ld + g * P + t]);
+    }
+    if (p.logits) {
+        const float mx = group_max(mk, 16);
+        const float e = t < P ? expf(mk - mx) : 0.f;
+        const float s = group_sum(e, 16);
+        mk = e / s;
+    }
+    const int halfk = (p.dil * (p.K - 1)) >> 1;
+    const float p0_w_ = (float)(halfk - p.pad + wo * p.stride) - halfk * p.os;
+    const float p0_h_ = (float)(halfk - p.pad + ho * p.stride) - halfk * p.os;
+    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * 256 + lane * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (int i = 0; i < p.K; ++i)
+        for (int j = 0; j < p.K; ++j) {
+            if (p.rc && i == p.K / 2 && j == p.K / 2) continue;
+            const int src = (lane & 48) | q;  // tap q's owner inside this 16-lane row
+            const float tw = __shfl(ow, src, 64), th = __shfl(oh, src, 64), wgt = __shfl(mk, src, 64);
+            const float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
+            const float loc_h = p0_h_ + (j * p.dil + th) * p.os;
+            if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)p.H && loc_w < (float)p.W)
+                bilinear4<T>(im, p.H, p.W, 256, loc_h, loc_w, wgt, acc);
+            ++q;
+        }
+    st4(reinterpret_cast<T*>(p.out) + r * 256 + lane * 4, acc);
+}
+
+template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
+    if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {
+        hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
+    } else {
+        const long total = p.rows * p.G * (p.D / 4);
+        hipLaunchKernelGGL((dcnv3_generic_kernel<T, OT>), dim3(cdiv(total, 256)), dim3(256), 0, s, p);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gp_dcnv3_forward(const void* in, const void* offset, const void* mask, void* out, int N, int H,
+                                int W, int G, int D, int K, int stride, int pad, int dil, float offset_scale,
+                                int remove_center, int im2col_step, int off_ld, int mask_ld,
+                                int mask_is_logits, int dtype, int om_dtype, void* stream) {
+    GP_REQUIRE(in && offset && mask && out, "gp_dcnv3_forward: null pointer");
+    GP_REQUIRE(N > 0 && H > 0 && W > 0 && G > 0 && D > 0 && K > 0 && stride > 0 && dil > 0 && pad >= 0,
+               "gp_dcnv3_forward: bad geometry");
+    GP_REQUIRE(D % 4 == 0, "gp_dcnv3_forward: group_channels=%d must be a multiple of 4", D);
+    GP_REQUIRE((dtype == GP_F32 || dtype == GP_F16) && (om_dtype == GP_F32 || om_dtype == GP_F16),
+               "gp_dcnv3_forward: bad dtype");
+    GP_REQUIRE(!remove_center || (K % 2 == 1), "remove_center is only compatible with odd kernel size.");
+    const int step = im2col_step < N ? im2col_step : N;
+    // dcnv3_cuda.cu:46-49
+    GP_REQUIRE(step > 0 && N % step == 0, "batch(%d) must divide im2col_step(%d)", N, step);
+    DcnKP p;
+    p.in = in; p.off = offset; p.mask = mask; p.out = out;
+    p.N = N; p.H = H; p.W = W; p.G = G; p.D = D; p.K = K; p.stride = stride; p.pad = pad; p.dil = dil;
+    p.rc = remove_center ? 1 : 0;
+    p.Ho = (H + 2 * pad - (dil * (K - 1) + 1)) / stride + 1;
+    p.Wo = (W + 2 * pad - (dil * (K - 1) + 1)) / stride + 1;
+    GP_REQUIRE(p.Ho > 0 && p.Wo > 0, "gp_dcnv3_forward: empty output");
+    const int P = K * K - p.rc;
+    GP_REQUIRE(off_ld >= G * P * 2 && mask_ld >= G * P, "gp_dcnv3_forward: off_ld/mask_ld too small");
+    p.off_ld = off_ld; p.mask_ld = mask_ld; p.logits = mask_is_logits ? 1 : 0; p.os = offset_scale;
+    p.rows = (long)N * p.Ho * p.Wo;
+    hipStream_t s = (hipStream_t)stream;
+    const int esz = dtype == GP_F16 ? 2 : 4, osz = om_dtype == GP_F16 ? 2 : 4;
+    // algorithmic bytes: input once + consumed offset/mask + output
+    const double bytes = (double)N * H * W * G * D * esz + (double)p.rows * G * P * 3 * osz + (double)p.rows * G * D * esz;
+    gp_timing_before(s, GP_KC_DCNV3, (double)p.rows * G * D * P * 8.0, bytes);
+    if (dtype == GP_F16 && om_dtype == GP_F16) launch<half_t, half_t>(p, s);
+    else if (dtype == GP_F16) launch<half_t, float>(p, s);
+    else if (om_dtype == GP_F16) launch<float, half_t>(p, s);
+    else launch<float, float>(p, s);
+    GP_LAUNCH_CHECK("gp_dcnv3_forward");
+}

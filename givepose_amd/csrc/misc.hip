@@ -1,0 +1,504 @@
+// Small / bandwidth-bound kernels of the PoseNet path (gfx950): ConvNeXt stem, bilinear x2,
+// deconv col2im, xyz out layer, tiny-Cin convolutions, SizeHead, pose tail, mask resize.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void store_T(half_t* p, float v) { *p = (half_t)v; }
+__device__ __forceinline__ void store_T(float* p, float v) { *p = v; }
+
+// ------------------------------------------------------------------------------------- stem
+// conv4x4 s4 (3 -> 128) + LayerNorm over the 128 channels.  Block = 16 output pixels of one row.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                   const float* __restrict__ lnb, T* __restrict__ out, int H,
+                                                   int W, float eps) {
+    constexpr int C0 = 128, PXB = 16;
+    __shared__ float w_s[48][C0];
+    __shared__ float in_s[12][PXB * 4];
+    __shared__ float r2[4][8];
+    const int Ho = H / 4, Wo = W / 4;
+    const int tid = threadIdx.x;
+    const int wblk = blockIdx.x % (Wo / PXB);
+    const int ho = (blockIdx.x / (Wo / PXB)) % Ho;
+    const int b = blockIdx.x / ((Wo / PXB) * Ho);
+    const int wo0 = wblk * PXB;
+    for (int i = tid; i < 48 * C0; i += 256) {  // w is (C0, 48) row-major -> transpose
+        const int co = i / 48, k = i - co * 48;
+        w_s[k][co] = w[i];
+    }
+    for (int i = tid; i < 12 * PXB * 4; i += 256) {
+        const int row = i / (PXB * 4), col = i - row * (PXB * 4);
+        const int c = row >> 2, kh = row & 3;
+        in_s[row][col] = img[(((long)b * 3 + c) * H + (ho * 4 + kh)) * W + wo0 * 4 + col];
+    }
+    __syncthreads();
+    const int ch = tid & 127, ph = tid >> 7;
+    float acc[8];
+    const float bv = bias[ch];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = bv;
+    for (int k = 0; k < 48; ++k) {
+        const float wv = w_s[k][ch];
+        const int row = k >> 2, kw = k & 3;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[p] += in_s[row][(ph * 8 + p) * 4 + kw] * wv;
+    }
+    // LayerNorm across 128 channels = 2 waves per pixel half
+    const int wave = tid >> 6, lane = tid & 63;
+    float s[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s[p] = group_sum(acc[p], 64);
+    if (lane == 0)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) r2[wave][p] = s[p];
+    __syncthreads();
+    float mean[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) mean[p] = (r2[ph * 2][p] + r2[ph * 2 + 1][p]) * (1.0f / C0);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        acc[p] -= mean[p];
+        s[p] = group_sum(acc[p] * acc[p], 64);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) r2[wave][p] = s[p];
+    __syncthreads();
+    const float gw = lnw[ch], gb = lnb[ch];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float var = (r2[ph * 2][p] + r2[ph * 2 + 1][p]) * (1.0f / C0);
+        const float v = acc[p] * rsqrtf(var + eps) * gw + gb;
+        store_T(out + ((((long)b * Ho + ho) * Wo + wo0 + ph * 8 + p) * C0 + ch), v);
+    }
+}
+
+// ------------------------------------------------------------------------------------- bilinear x2
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                         int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int CT = C / VEC, Ho = 2 * H, Wo = 2 * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Ho * Wo * CT) return;
+    const int cs = (int)(idx % CT);
+    long t = idx / CT;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    // align_corners=True: src = dst * (in-1)/(out-1)
+    const float sy = (float)(H - 1) / (float)(Ho - 1) * oy, sx = (float)(W - 1) / (float)(Wo - 1) * ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const T* xb = x + (b * H * W) * C + cs * VEC;
+    const Vec16<T> v00 = load16<T>(xb + ((long)y0 * W + x0) * C), v01 = load16<T>(xb + ((long)y0 * W + x1) * C),
+                   v10 = load16<T>(xb + ((long)y1 * W + x0) * C), v11 = load16<T>(xb + ((long)y1 * W + x1) * C);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        o.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
+    store16<T>(y + ((b * Ho + oy) * Wo + ox) * C + cs * VEC, o);
+}
+
+// ------------------------------------------------------------------------------------- deconv col2im
+// out[b][y][x][co] = sum over (ky,kx) with y = 2i-1+ky, x = 2j-1+kx of cols[(b,i,j)][(ky*3+kx)*C + co]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, T* __restrict__ out, int B,
+                                                     int H, int W, int C) {
+    const int C4 = C / 4, Ho = 2 * H, Wo = 2 * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Ho * Wo * C4) return;
+    const int c4 = (int)(idx % C4);
+    long t = idx / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = oy + 1 - ky;
+        if (ty < 0 || (ty & 1)) continue;
+        const int i = ty >> 1;
+        if (i >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ox + 1 - kx;
+            if (tx < 0 || (tx & 1)) continue;
+            const int j = tx >> 1;
+            if (j >= W) continue;
+            a += *reinterpret_cast<const f32x4*>(cols + ((b * H + i) * W + j) * (9L * C) + (ky * 3 + kx) * C + c4 * 4);
+        }
+    }
+    T* o = out + ((b * Ho + oy) * Wo + ox) * C + c4 * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) store_T(o + e, a[e]);
+}
+
+// ------------------------------------------------------------------------------------- xyz out layer
+template <typename T>
+__global__ __launch_bounds__(256) void xyz_out_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out_nchw,
+                                                      float* __restrict__ out_nhwc4, long rows, int HW, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int chunks = C / VEC;                  // 16-B chunks per pixel
+    const int LPP = chunks < 64 ? chunks : 64;   // lanes per pixel (power of two)
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPP, l = lane % LPP;
+    const int ppw = 64 / LPP;                    // pixels per wave per step
+    const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row = wave_id * ppw + sub;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (row < rows) {
+        for (int c = l; c < chunks; c += LPP) {
+            const Vec16<T> v = load16<T>(x + row * C + c * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float f = v.get(e);
+                const int ch = c * VEC + e;
+                a0 += f * w[ch];
+                a1 += f * w[C + ch];
+                a2 += f * w[2 * C + ch];
+            }
+        }
+    }
+    a0 = group_sum(a0, LPP); a1 = group_sum(a1, LPP); a2 = group_sum(a2, LPP);
+    if (row < rows && l == 0) {
+        a0 += bias[0]; a1 += bias[1]; a2 += bias[2];
+        const long b = row / HW, pix = row - b * HW;
+        out_nchw[(b * 3 + 0) * HW + pix] = a0;
+        out_nchw[(b * 3 + 1) * HW + pix] = a1;
+        out_nchw[(b * 3 + 2) * HW + pix] = a2;
+        *reinterpret_cast<f32x4*>(out_nhwc4 + row * 4) = f32x4{a0, a1, a2, 0.f};
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restrict__ xyz4, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ y,
+                                                           long rows, int Cout) {
+    constexpr int VEC = Vec16<T>::N;
+    const int CT = Cout / VEC;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * CT) return;
+    const int cs = (int)(idx % CT);
+    const long row = idx / CT;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + row * 4);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int n = cs * VEC + e;
+        o.set(e, w[n * 3] * p[0] + w[n * 3 + 1] * p[1] + w[n * 3 + 2] * p[2] + bias[n]);
+    }
+    store16<T>(y + row * Cout + cs * VEC, o);
+}
+
+// ------------------------------------------------------------------------------------- tiny-Cin 3x3 s2 conv
+// input channels: c < 3 from xyz4 (B*R*R, 4); c in {3,4} from coord2d (B,2,R,R) when CIN == 5.
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __restrict__ xyz4,
+                                                                const float* __restrict__ coord2d,
+                                                                const float* __restrict__ w, T* __restrict__ y,
+                                                                int B, int R, int Cout) {
+    constexpr int KK = CIN * 9;
+    extern __shared__ float w_s[];  // [KK][Cout]
+    for (int i = threadIdx.x; i < KK * Cout; i += 256) {
+        const int co = i / KK, k = i - co * KK;  // w is (Cout, CIN, 3, 3) row-major
+        w_s[k * Cout + co] = w[i];
+    }
+    __syncthreads();
+    const int Ro = R / 2, CQ = Cout / 4, PB = 256 / CQ;
+    const int cq = threadIdx.x % CQ;
+    const long pix = (long)blockIdx.x * PB + threadIdx.x / CQ;
+    if (pix >= (long)B * Ro * Ro) return;
+    const int wo = (int)(pix % Ro);
+    const long t = pix / Ro;
+    const int ho = (int)(t % Ro);
+    const long b = t / Ro;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if ((unsigned)hi >= (unsigned)R) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if ((unsigned)wi >= (unsigned)R) continue;
+            const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + hi) * R + wi) * 4);
+            float in[CIN];
+            in[0] = p[0]; in[1] = p[1]; in[2] = p[2];
+            if constexpr (CIN == 5) {
+                in[3] = coord2d[((b * 2 + 0) * R + hi) * R + wi];
+                in[4] = coord2d[((b * 2 + 1) * R + hi) * R + wi];
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + (c * 9 + kh * 3 + kw) * Cout + cq * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += in[c] * wv[e];
+            }
+        }
+    }
+    T* o = y + pix * Cout + cq * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) store_T(o + e, acc[e]);
+}
+
+// ------------------------------------------------------------------------------------- SizeHead
+template <typename T>
+__global__ __launch_bounds__(256) void size_head_kernel(const T* __restrict__ feat, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2,
+                                                        const float* __restrict__ mean_size, float* __restrict__ size,
+                                                        int HW, int C, int F) {
+    extern __shared__ float sh[];  // [C] pooled + [F] hidden
+    float* pooled = sh;
+    float* hid = sh + C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float m = -INFINITY;
+        for (int p = 0; p < HW; ++p) m = fmaxf(m, (float)feat[((long)b * HW + p) * C + c]);
+        pooled[c] = m;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int f = wave; f < F; f += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += pooled[c] * w1[(long)f * C + c];
+        a = group_sum(a, 64);
+        if (lane == 0) hid[f] = fmaxf(a + b1[f], 0.f);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float ms[3] = {mean_size[b * 3], mean_size[b * 3 + 1], mean_size[b * 3 + 2]};
+        const float nrm = sqrtf(ms[0] * ms[0] + ms[1] * ms[1] + ms[2] * ms[2]);
+        for (int o = 0; o < 3; ++o) {
+            float a = 0.f;
+            for (int f = lane; f < F; f += 64) a += hid[f] * w2[o * F + f];
+            a = group_sum(a, 64);
+            if (lane == 0) size[b * 3 + o] = a + b2[o] + ms[o] / nrm;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------- pose tail
+__global__ __launch_bounds__(64) void pose_tail_kernel(const float* __restrict__ h, const float* __restrict__ hz,
+                                                       int ldh, const float* __restrict__ w_r,
+                                                       const float* __restrict__ b_r, const float* __restrict__ w_t,
+                                                       const float* __restrict__ b_t, const float* __restrict__ w_z,
+                                                       const float* __restrict__ b_z, const float* __restrict__ cam_K,
+                                                       const float* __restrict__ bbox_center,
+                                                       const float* __restrict__ resize_ratio,
+                                                       const float* __restrict__ roi_wh, int wild6d, int site,
+                                                       float* __restrict__ rot6d, float* __restrict__ pred_t,
+                                                       float* __restrict__ rot_allo, float* __restrict__ rot_ego,
+                                                       float* __restrict__ trans) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + (long)b * ldh + lane * 4);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(hz + (long)b * ldh + lane * 4);
+    float o[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float* wrow = i < 6 ? w_r + i * 256 : (i < 8 ? w_t + (i - 6) * 256 : w_z);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + lane * 4);
+        const f32x4 xv = i < 8 ? hv : zv;
+        float a = wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+        a = group_sum(a, 64);
+        o[i] = a + (i < 6 ? b_r[i] : (i < 8 ? b_t[i - 6] : b_z[0]));
+    }
+    if (lane != 0) return;
+    for (int i = 0; i < 6; ++i) rot6d[b * 6 + i] = o[i];
+    for (int i = 0; i < 3; ++i) pred_t[b * 3 + i] = o[6 + i];
+    // rot6d -> R (pose_utils/rot_reps.py:34-55), F.normalize eps 1e-12
+    float x[3] = {o[0], o[1], o[2]}, yr[3] = {o[3], o[4], o[5]}, z[3], y[3];
+    float n = fmaxf(sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]), 1e-12f);
+    for (int i = 0; i < 3; ++i) x[i] /= n;
+    z[0] = x[1] * yr[2] - x[2] * yr[1]; z[1] = x[2] * yr[0] - x[0] * yr[2]; z[2] = x[0] * yr[1] - x[1] * yr[0];
+    n = fmaxf(sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]), 1e-12f);
+    for (int i = 0; i < 3; ++i) z[i] /= n;
+    y[0] = z[1] * x[2] - z[2] * x[1]; y[1] = z[2] * x[0] - z[0] * x[2]; y[2] = z[0] * x[1] - z[1] * x[0];
+    float Ra[9];
+    for (int i = 0; i < 3; ++i) { Ra[i * 3] = x[i]; Ra[i * 3 + 1] = y[i]; Ra[i * 3 + 2] = z[i]; }
+    for (int i = 0; i < 9; ++i) rot_allo[b * 9 + i] = Ra[i];
+    // centroid / z back-projection (pose_from_pred_centroid_z.py:75-121)
+    const float* K = cam_K + b * 9;
+    const float c0 = site ? o[6] : o[6] * 0.f, c1 = site ? o[7] : o[7] * 0.f;
+    const float cx = c0 * roi_wh[b * 2] + bbox_center[b * 2], cy = c1 * roi_wh[b * 2 + 1] + bbox_center[b * 2 + 1];
+    float zz = o[8] * resize_ratio[b];
+    if (wild6d) zz = zz * cam_K[0] / 590.f;
+    const float tr[3] = {zz * (cx - K[2]) / K[0], zz * (cy - K[5]) / K[4], zz};
+    for (int i = 0; i < 3; ++i) trans[b * 3 + i] = tr[i];
+    // allocentric -> egocentric (pose_utils/utils.py:29-84): float32 ray, float64 rotation
+    const float tn = sqrtf(tr[0] * tr[0] + tr[1] * tr[1] + tr[2] * tr[2]);
+    const float ray[3] = {tr[0] / tn, tr[1] / tn, tr[2] / tn};
+    const double angle = acos((double)ray[2]);
+    if (angle > 0.0) {
+        double ax = -(double)ray[1], ay = (double)ray[0], az = 0.0;  // cross((0,0,1), ray)
+        const double an = sqrt(ax * ax + ay * ay + az * az);
+        ax /= an; ay /= an; az /= an;
+        const double c = cos(angle), s = sin(angle), Cc = 1.0 - c;
+        const double xs = ax * s, ys = ay * s, zs = az * s, xC = ax * Cc, yC = ay * Cc, zC = az * Cc;
+        const double xyC = ax * yC, yzC = ay * zC, zxC = az * xC;
+        const double M[9] = {ax * xC + c, xyC - zs, zxC + ys, xyC + zs, ay * yC + c, yzC - xs,
+                             zxC - ys, yzC + xs, az * zC + c};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < 3; ++k) a += M[i * 3 + k] * (double)Ra[k * 3 + j];
+                rot_ego[b * 9 + i * 3 + j] = (float)a;
+            }
+    } else {
+        for (int i = 0; i < 9; ++i) rot_ego[b * 9 + i] = Ra[i];
+    }
+}
+
+__global__ void mask_resize_kernel(const float* __restrict__ m, float* __restrict__ out, int B, int S, int R) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * R * R) return;
+    const int x = (int)(idx % R);
+    const long t = idx / R;
+    const int y = (int)(t % R);
+    const long b = t / R;
+    // legacy nearest: src = floor(dst * S / R)
+    const int sy = min((int)floorf(y * ((float)S / R)), S - 1), sx = min((int)floorf(x * ((float)S / R)), S - 1);
+    out[idx] = m[(b * S + sy) * S + sx];
+}
+
+}  // namespace
+
+#define GP_DT_OK(dt) GP_REQUIRE((dt) == GP_F32 || (dt) == GP_F16, "bad dtype %d", (dt))
+
+extern "C" int gp_convnext_stem(const float* img, const float* w, const float* b, const float* ln_w,
+                                const float* ln_b, void* out, int B, int H, int W, int C0, float eps, int dtype,
+                                void* stream) {
+    GP_REQUIRE(img && w && b && ln_w && ln_b && out && B > 0, "gp_convnext_stem: bad argument");
+    GP_DT_OK(dtype);
+    GP_REQUIRE(C0 == 128, "gp_convnext_stem: C0=%d unsupported (128)", C0);
+    GP_REQUIRE(H % 4 == 0 && W % 64 == 0, "gp_convnext_stem: H,W=%d,%d must be multiples of 4,64", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const long px = (long)B * (H / 4) * (W / 4);
+    gp_timing_before(s, GP_KC_SMALL, 2.0 * px * 48 * C0, (double)B * 3 * H * W * 4 + (double)px * C0 * (dtype == GP_F16 ? 2 : 4));
+    dim3 grid(B * (H / 4) * (W / 4 / 16));
+    if (dtype == GP_F16) hipLaunchKernelGGL(stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
+    else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (float*)out, H, W, eps);
+    GP_LAUNCH_CHECK("gp_convnext_stem");
+}
+
+extern "C" int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    GP_REQUIRE(x && y && B > 0 && H > 1 && W > 1, "gp_upsample_bilinear2x: bad argument");
+    GP_DT_OK(dtype);
+    const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
+    GP_REQUIRE(C % vec == 0, "gp_upsample_bilinear2x: C=%d", C);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 4 * H * W * (C / vec);
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 8.0 * total * vec, (double)B * H * W * C * esz * 5);
+    if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, B, H, W, C);
+    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
+    GP_LAUNCH_CHECK("gp_upsample_bilinear2x");
+}
+
+extern "C" int gp_deconv_col2im(const float* cols, void* out, int B, int H, int W, int C, int dtype, void* stream) {
+    GP_REQUIRE(cols && out && B > 0 && C % 4 == 0, "gp_deconv_col2im: bad argument");
+    GP_DT_OK(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * 4 * H * W * (C / 4);
+    gp_timing_before(s, GP_KC_ELEMENTWISE, (double)B * H * W * 9 * C, (double)B * H * W * 9 * C * 4 + (double)total * 4 * (dtype == GP_F16 ? 2 : 4));
+    if (dtype == GP_F16) hipLaunchKernelGGL(col2im_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, cols, (half_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL(col2im_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, cols, (float*)out, B, H, W, C);
+    GP_LAUNCH_CHECK("gp_deconv_col2im");
+}
+
+extern "C" int gp_xyz_out_layer(const void* x, const float* w, const float* b, float* out_nchw, float* out_nhwc4,
+                                int B, int HW, int C, int dtype, void* stream) {
+    GP_REQUIRE(x && w && b && out_nchw && out_nhwc4 && B > 0, "gp_xyz_out_layer: bad argument");
+    GP_DT_OK(dtype);
+    const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz, chunks = C / vec;
+    GP_REQUIRE(C % vec == 0 && (chunks & (chunks - 1)) == 0, "gp_xyz_out_layer: C=%d", C);
+    const int LPP = chunks < 64 ? chunks : 64, ppw = 64 / LPP;
+    const long rows = (long)B * HW;
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 6.0 * rows * C, (double)rows * C * esz + rows * 28.0);
+    dim3 grid(cdiv(rows, 4L * ppw));
+    if (dtype == GP_F16) hipLaunchKernelGGL(xyz_out_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, w, b, out_nchw, out_nhwc4, rows, HW, C);
+    else hipLaunchKernelGGL(xyz_out_kernel<float>, grid, dim3(256), 0, s, (const float*)x, w, b, out_nchw, out_nhwc4, rows, HW, C);
+    GP_LAUNCH_CHECK("gp_xyz_out_layer");
+}
+
+extern "C" int gp_pointwise_k3(const float* xyz4, const float* w, const float* b, void* y, long rows, int Cout,
+                               int dtype, void* stream) {
+    GP_REQUIRE(xyz4 && w && b && y && rows > 0, "gp_pointwise_k3: bad argument");
+    GP_DT_OK(dtype);
+    const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
+    GP_REQUIRE(Cout % vec == 0, "gp_pointwise_k3: Cout=%d", Cout);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = rows * (Cout / vec);
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 6.0 * rows * Cout, rows * 16.0 + (double)rows * Cout * esz);
+    if (dtype == GP_F16) hipLaunchKernelGGL(pointwise_k3_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (half_t*)y, rows, Cout);
+    else hipLaunchKernelGGL(pointwise_k3_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (float*)y, rows, Cout);
+    GP_LAUNCH_CHECK("gp_pointwise_k3");
+}
+
+template <int CIN>
+static int launch_smallcin(const float* xyz4, const float* coord2d, const float* w, void* y, int B, int R, int Cout,
+                           int dtype, void* stream, const char* name) {
+    GP_REQUIRE(xyz4 && w && y && B > 0 && R % 2 == 0, "%s: bad argument", name);
+    GP_DT_OK(dtype);
+    GP_REQUIRE(Cout % 4 == 0 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0, "%s: Cout=%d", name, Cout);
+    hipStream_t s = (hipStream_t)stream;
+    const long pix = (long)B * (R / 2) * (R / 2);
+    const int PB = 256 / (Cout / 4);
+    const size_t lds = (size_t)CIN * 9 * Cout * sizeof(float);
+    gp_timing_before(s, GP_KC_SMALL, 2.0 * pix * CIN * 9 * Cout, (double)B * R * R * CIN * 4 + (double)pix * Cout * (dtype == GP_F16 ? 2 : 4));
+    if (dtype == GP_F16)
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix, PB)), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
+    else
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix, PB)), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
+    GP_LAUNCH_CHECK(name);
+}
+
+extern "C" int gp_pnp_conv1(const float* xyz4, const float* coord2d, const float* w, void* y, int B, int R,
+                            int Cout, int dtype, void* stream) {
+    GP_REQUIRE(coord2d != nullptr, "gp_pnp_conv1: null coord2d");
+    return launch_smallcin<5>(xyz4, coord2d, w, y, B, R, Cout, dtype, stream, "gp_pnp_conv1");
+}
+
+extern "C" int gp_xyz_conv3x3_s2(const float* xyz4, const float* w, void* y, int B, int R, int Cout, int dtype,
+                                 void* stream) {
+    return launch_smallcin<3>(xyz4, nullptr, w, y, B, R, Cout, dtype, stream, "gp_xyz_conv3x3_s2");
+}
+
+extern "C" int gp_size_head(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                            const float* mean_size, float* size, int B, int HW, int C, int F, int dtype,
+                            void* stream) {
+    GP_REQUIRE(feat && w1 && b1 && w2 && b2 && mean_size && size && B > 0, "gp_size_head: bad argument");
+    GP_DT_OK(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 2.0 * B * (C * F + 3 * F), (double)B * HW * C * (dtype == GP_F16 ? 2 : 4));
+    const size_t lds = (size_t)(C + F) * sizeof(float);
+    if (dtype == GP_F16) hipLaunchKernelGGL(size_head_kernel<half_t>, dim3(B), dim3(256), lds, s, (const half_t*)feat, w1, b1, w2, b2, mean_size, size, HW, C, F);
+    else hipLaunchKernelGGL(size_head_kernel<float>, dim3(B), dim3(256), lds, s, (const float*)feat, w1, b1, w2, b2, mean_size, size, HW, C, F);
+    GP_LAUNCH_CHECK("gp_size_head");
+}
+
+extern "C" int gp_pose_tail(const float* h, const float* hz, int ldh, const float* w_r, const float* b_r,
+                            const float* w_t, const float* b_t, const float* w_z, const float* b_z,
+                            const float* cam_K, const float* bbox_center, const float* resize_ratio,
+                            const float* roi_wh, int wild6d, int site_centroid, float* rot6d, float* pred_t,
+                            float* rot_allo, float* rot_ego, float* trans, int B, void* stream) {
+    GP_REQUIRE(h && hz && w_r && b_r && w_t && b_t && w_z && b_z && cam_K && bbox_center && resize_ratio && roi_wh &&
+                   rot6d && pred_t && rot_allo && rot_ego && trans && B > 0 && ldh >= 256 && ldh % 4 == 0,
+               "gp_pose_tail: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 2.0 * B * 9 * 256, B * 2048.0);
+    hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(64), 0, s, h, hz, ldh, w_r, b_r, w_t, b_t, w_z, b_z, cam_K,
+                       bbox_center, resize_ratio, roi_wh, wild6d, site_centroid, rot6d, pred_t, rot_allo, rot_ego, trans);
+    GP_LAUNCH_CHECK("gp_pose_tail");
+}
+
+extern "C" int gp_mask_resize_nearest(const float* mask, float* out, int B, int S, int R, void* stream) {
+    GP_REQUIRE(mask && out && B > 0 && S > 0 && R > 0, "gp_mask_resize_nearest: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * R * R;
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 0.0, total * 8.0);
+    hipLaunchKernelGGL(mask_resize_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, mask, out, B, S, R);
+    GP_LAUNCH_CHECK("gp_mask_resize_nearest");
+}

@@ -1,0 +1,365 @@
+// Bandwidth-bound normalisation kernels on channels-last tensors (gfx950):
+//   depth-wise KxK conv + LayerNorm (+GELU), row LayerNorm, GroupNorm statistics / apply.
+// Common mapping: a pixel's C channels are spread over CT = C / VEC consecutive threads, VEC = one
+// 16-byte vector (8 halfs / 4 floats), so every global access is a full 16 B per lane and a pixel row
+// is one contiguous run per CT lanes; 256-thread blocks hold PG = 256 / CT pixel groups.
+#include "common.hpp"
+
+namespace {
+
+// Sum NV values over the CT threads (CT power of two, 16..256, aligned) that share this thread's
+// pixel group.  red: LDS scratch of 4*NV floats.
+template <int NV>
+__device__ __forceinline__ void pixel_group_sum(float (&v)[NV], int CT, float* red) {
+    if (CT <= 64) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = group_sum(v[i], CT);
+    } else {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = group_sum(v[i], 64);
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+        __syncthreads();
+        const int wpg = CT >> 6, w0 = (threadIdx.x / CT) * wpg;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float s = 0.f;
+            for (int w = 0; w < wpg; ++w) s += red[(w0 + w) * NV + i];
+            v[i] = s;
+        }
+    }
+}
+
+template <typename T> __device__ __forceinline__ void load_f32(const float* p, float* o);
+template <> __device__ __forceinline__ void load_f32<half_t>(const float* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+}
+template <> __device__ __forceinline__ void load_f32<float>(const float* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    for (int i = 0; i < 4; ++i) o[i] = a[i];
+}
+
+// ---------------------------------------------------------------------------- dwconv + LN (+act)
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, T* __restrict__ y, int H,
+                                                        int W, int C, float eps, int act, long n_pixels) {
+    constexpr int VEC = Vec16<T>::N, PPT = 4, R = KS / 2;
+    __shared__ float red[4 * PPT];
+    const int CT = C / VEC, PG = 256 / CT;
+    const int cs = threadIdx.x % CT, pg = threadIdx.x / CT;
+    const long strip = (long)blockIdx.x * PG + pg;
+    const long pix0 = strip * PPT;
+    const bool valid = pix0 < n_pixels;
+    const int w0 = (int)(pix0 % W);
+    const long t = pix0 / W;
+    const int h = (int)(t % H);
+    const long b = t / H;
+    float acc[PPT][VEC];
+    {
+        float bv[VEC];
+        load_f32<T>(bias + cs * VEC, bv);
+#pragma unroll
+        for (int p = 0; p < PPT; ++p)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[p][e] = bv[e];
+    }
+    if (valid) {
+        const T* xb = x + (b * H * W) * C + cs * VEC;
+        for (int kh = 0; kh < KS; ++kh) {
+            const int hi = h + kh - R;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            Vec16<T> in[KS + PPT - 1];
+#pragma unroll
+            for (int c = 0; c < KS + PPT - 1; ++c) {
+                const int wi = w0 + c - R;
+                in[c] = ((unsigned)wi < (unsigned)W) ? load16<T>(xb + ((long)hi * W + wi) * C) : zero16<T>();
+            }
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                float wv[VEC];
+                load_f32<T>(wt + (long)(kh * KS + kw) * C + cs * VEC, wv);
+#pragma unroll
+                for (int p = 0; p < PPT; ++p)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[p][e] += in[p + kw].get(e) * wv[e];
+            }
+        }
+    }
+    // LayerNorm over C per pixel (two-pass: mean, then centred variance)
+    float s[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        s[p] = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[p] += acc[p][e];
+    }
+    pixel_group_sum<PPT>(s, CT, red);
+    float v[PPT];
+    const float invC = 1.0f / C;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const float mean = s[p] * invC;
+        v[p] = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            acc[p][e] -= mean;
+            v[p] += acc[p][e] * acc[p][e];
+        }
+    }
+    pixel_group_sum<PPT>(v, CT, red);
+    if (!valid) return;
+    float gw[VEC], gb[VEC];
+    load_f32<T>(lnw + cs * VEC, gw);
+    load_f32<T>(lnb + cs * VEC, gb);
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        if (pix0 + p >= n_pixels) break;
+        const float rstd = rsqrtf(v[p] * invC + eps);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, apply_act(acc[p][e] * rstd * gw[e] + gb[e], act));
+        store16<T>(y + (pix0 + p) * C + cs * VEC, o);
+    }
+}
+
+// ---------------------------------------------------------------------------- row LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* __restrict__ y,
+                                                        long rows, int C, float eps) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float red[4];
+    const int CT = C / VEC, PG = 256 / CT;
+    const int cs = threadIdx.x % CT;
+    const long row = (long)blockIdx.x * PG + threadIdx.x / CT;
+    const bool valid = row < rows;
+    float a[VEC];
+    if (valid) {
+        const Vec16<T> v = load16<T>(x + row * C + cs * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = v.get(e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+    }
+    float s[1] = {0.f};
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[0] += a[e];
+    pixel_group_sum<1>(s, CT, red);
+    const float mean = s[0] / C;
+    float q[1] = {0.f};
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        a[e] -= mean;
+        q[0] += a[e] * a[e];
+    }
+    pixel_group_sum<1>(q, CT, red);
+    if (!valid) return;
+    const float rstd = rsqrtf(q[0] / C + eps);
+    float gw[VEC], gb[VEC];
+    load_f32<T>(w + cs * VEC, gw);
+    load_f32<T>(b + cs * VEC, gb);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, a[e] * rstd * gw[e] + gb[e]);
+    store16<T>(y + row * C + cs * VEC, o);
+}
+
+// ---------------------------------------------------------------------------- GroupNorm
+constexpr int GN_PXB = 256;  // pixels per statistics block
+
+// partial[((b*chunks + chunk)*G + g)*2 + {0,1}] = (sum, sum of squares) of this chunk, fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                         int HW, int C, int G) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float part[256][4][2];
+    const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
+    const int NG = cpg >= VEC ? 1 : VEC / cpg;  // groups covered by one 16-B vector (<= 4)
+    const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
+    const int b = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    const int p0 = chunk * GN_PXB, p1 = min(HW, p0 + GN_PXB);
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* xb = x + ((long)b * HW) * C + cs * VEC;
+    for (int p = p0 + pl; p < p1; p += PG) {
+        const Vec16<T> v = load16<T>(xb + (long)p * C);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float f = v.get(e);
+            const int j = NG == 1 ? 0 : e / cpg;
+            sm[j] += f;
+            sq[j] += f * f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        part[threadIdx.x][j][0] = sm[j];
+        part[threadIdx.x][j][1] = sq[j];
+    }
+    __syncthreads();
+    const int g = threadIdx.x;
+    if (g < G) {
+        float a = 0.f, q = 0.f;
+        int cs0, cs1, j;
+        if (NG == 1) {
+            const int tpg = cpg / VEC;  // threads per group
+            cs0 = g * tpg; cs1 = cs0 + tpg; j = 0;
+        } else {
+            cs0 = g / NG; cs1 = cs0 + 1; j = g % NG;
+        }
+        for (int l = 0; l < PG; ++l)
+            for (int c = cs0; c < cs1; ++c) {
+                a += part[l * CT + c][j][0];
+                q += part[l * CT + c][j][1];
+            }
+        float* o = partial + (((long)b * chunks + chunk) * G + g) * 2;
+        o[0] = a;
+        o[1] = q;
+    }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int BG, int G,
+                                   int chunks, float inv_count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G;
+    double a = 0.0, q = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        const float* p = partial + (((long)b * chunks + c) * G + g) * 2;
+        a += p[0];
+        q += p[1];
+    }
+    const double mean = a * inv_count;
+    double var = q * inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ w, const float* __restrict__ bb,
+                                                       T* __restrict__ y, int HW, int C, int G, int act, int ldy) {
+    constexpr int VEC = Vec16<T>::N;
+    const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
+    const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
+    float sc[VEC], sh[VEC];
+    {
+        float gw[VEC], gb[VEC];
+        load_f32<T>(w + cs * VEC, gw);
+        load_f32<T>(bb + cs * VEC, gb);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int g = (cs * VEC + e) / cpg;
+            const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
+            sc[e] = rstd * gw[e];
+            sh[e] = gb[e] - mean * sc[e];
+        }
+    }
+    const T* xb = x + ((long)b * HW) * C + cs * VEC;
+    T* yb = y + ((long)b * HW) * ldy + cs * VEC;
+    for (int p = p0 + pl; p < p1; p += PG) {
+        const Vec16<T> v = load16<T>(xb + (long)p * C);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v.get(e) * sc[e] + sh[e], act));
+        store16<T>(yb + (long)p * ldy, o);
+    }
+}
+
+bool ct_ok(int C, int esz) {
+    const int vec = 16 / esz;
+    if (C % vec) return false;
+    const int ct = C / vec;
+    return ct >= 1 && ct <= 256 && (ct & (ct - 1)) == 0;
+}
+
+}  // namespace
+
+extern "C" int gp_dwconv_ln(const void* x, const float* wt, const float* bias, const float* ln_w,
+                            const float* ln_b, void* y, int B, int H, int W, int C, int KS, float eps, int act,
+                            long n_pixels, int dtype, void* stream) {
+    GP_REQUIRE(x && wt && bias && ln_w && ln_b && y, "gp_dwconv_ln: null pointer");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_dwconv_ln: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4;
+    GP_REQUIRE(ct_ok(C, esz) && C / (16 / esz) >= 16, "gp_dwconv_ln: unsupported C=%d", C);
+    GP_REQUIRE(KS == 3 || KS == 7, "gp_dwconv_ln: KS=%d unsupported (3 or 7)", KS);
+    GP_REQUIRE(W % 4 == 0, "gp_dwconv_ln: W=%d must be a multiple of 4", W);
+    const long total = (long)B * H * W;
+    GP_REQUIRE(n_pixels > 0 && n_pixels <= total, "gp_dwconv_ln: n_pixels out of range");
+    const int CT = C / (16 / esz), PG = 256 / CT;
+    const long strips = (n_pixels + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
+    dim3 grid(cdiv(strips, PG));
+#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels)
+    if (dtype == GP_F16) { if (KS == 7) GP_DW(half_t, 7); else GP_DW(half_t, 3); }
+    else { if (KS == 7) GP_DW(float, 7); else GP_DW(float, 3); }
+#undef GP_DW
+    GP_LAUNCH_CHECK("gp_dwconv_ln");
+}
+
+extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,
+                            int dtype, void* stream) {
+    GP_REQUIRE(x && w && b && y && rows > 0, "gp_layernorm: bad argument");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_layernorm: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4;
+    GP_REQUIRE(ct_ok(C, esz), "gp_layernorm: unsupported C=%d", C);
+    const int CT = C / (16 / esz), PG = 256 / CT;
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_NORM, 8.0 * rows * C, (double)rows * C * esz * 2);
+    if (dtype == GP_F16)
+        hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps);
+    GP_LAUNCH_CHECK("gp_layernorm");
+}
+
+extern "C" int gp_groupnorm_chunks(int HW) { return cdiv(HW, GN_PXB); }
+
+extern "C" int gp_groupnorm_stats(const void* x, float* partial, float* stats, int B, int HW, int C, int G,
+                                  float eps, int dtype, void* stream) {
+    GP_REQUIRE(x && partial && stats && B > 0 && HW > 0, "gp_groupnorm_stats: bad argument");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_stats: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
+    GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_stats: unsupported C=%d G=%d", C, G);
+    const int cpg = C / G;
+    GP_REQUIRE((cpg >= vec && cpg % vec == 0) || (cpg < vec && vec % cpg == 0 && vec / cpg <= 4),
+               "gp_groupnorm_stats: channels per group %d unsupported", cpg);
+    const int chunks = cdiv(HW, GN_PXB);
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_NORM, 3.0 * B * HW * C, (double)B * HW * C * esz);
+    if (dtype == GP_F16)
+        hipLaunchKernelGGL(gn_partial_kernel<half_t>, dim3(chunks, B), dim3(256), 0, s, (const half_t*)x, partial, HW, C, G);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, B), dim3(256), 0, s, (const float*)x, partial, HW, C, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv((long)B * G, 256)), dim3(256), 0, s, partial, stats, B * G, G, chunks,
+                       1.0f / ((float)HW * cpg), eps);
+    GP_LAUNCH_CHECK("gp_groupnorm_stats");
+}
+
+extern "C" int gp_groupnorm_apply(const void* x, const float* stats, const float* w, const float* b, void* y,
+                                  int B, int HW, int C, int G, int act, int ldy, int dtype, void* stream) {
+    GP_REQUIRE(x && stats && w && b && y && B > 0 && HW > 0, "gp_groupnorm_apply: bad argument");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4;
+    GP_REQUIRE(ct_ok(C, esz) && G > 0 && C % G == 0, "gp_groupnorm_apply: unsupported C=%d G=%d", C, G);
+    GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
+    dim3 grid(cdiv(HW, GN_PXB), B);
+    if (dtype == GP_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, stats, w, b, (half_t*)y, HW, C, G, act, ldy);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, w, b, (float*)y, HW, C, G, act, ldy);
+    GP_LAUNCH_CHECK("gp_groupnorm_apply");
+}

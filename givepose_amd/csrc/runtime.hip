@@ -1,0 +1,145 @@
+// Error reporting, device info, hipGraph capture and per-launch event timing.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+thread_local char gp_err_buf[512] = {0};
+
+int gp_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(gp_err_buf, sizeof(gp_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* gp_last_error(void) { return gp_err_buf; }
+extern "C" int gp_version(void) { return 100; }
+
+extern "C" int gp_device_info(int* cu_count, char* arch, int arch_len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipGetDevice failed");
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipGetDeviceProperties failed");
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (arch && arch_len > 0) {
+        strncpy(arch, p.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------ graphs
+extern "C" int gp_graph_begin(void* stream) {
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    return GP_OK;
+}
+extern "C" int gp_graph_end(void* stream, void** graph_exec_out) {
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+    if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    *graph_exec_out = (void*)ge;
+    return GP_OK;
+}
+extern "C" int gp_graph_launch(void* graph_exec, void* stream) {
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+    if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "hipGraphLaunch: %s", hipGetErrorString(e));
+    return GP_OK;
+}
+extern "C" int gp_graph_destroy(void* graph_exec) {
+    if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+    return GP_OK;
+}
+
+// ------------------------------------------------------------------------------------ timing
+namespace {
+struct Rec {
+    hipEvent_t a, b;
+    int cls;
+    double flops, bytes;
+};
+bool g_timing = false;
+hipStream_t g_tstream = nullptr;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+Rec g_cur;
+bool g_open = false;
+struct Acc {
+    long n = 0;
+    double ms = 0, flops = 0, bytes = 0;
+} g_acc[GP_KC_COUNT];
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void gp_timing_before(hipStream_t s, int cls, double flops, double bytes) {
+    if (!g_timing || s != g_tstream) return;
+    g_cur.a = get_event();
+    g_cur.b = get_event();
+    g_cur.cls = cls;
+    g_cur.flops = flops;
+    g_cur.bytes = bytes;
+    hipEventRecord(g_cur.a, s);
+    g_open = true;
+}
+
+int gp_timing_after(const char*) {
+    if (g_open) {
+        hipEventRecord(g_cur.b, g_tstream);
+        g_recs.push_back(g_cur);
+        g_open = false;
+    }
+    return GP_OK;
+}
+
+extern "C" int gp_timing_begin(void* stream) {
+    g_tstream = (hipStream_t)stream;
+    g_recs.clear();
+    for (auto& a : g_acc) a = Acc();
+    g_timing = true;
+    return GP_OK;
+}
+
+extern "C" int gp_timing_end(void) {
+    g_timing = false;
+    hipError_t e = hipStreamSynchronize(g_tstream);
+    if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "timing sync: %s", hipGetErrorString(e));
+    for (auto& r : g_recs) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        Acc& a = g_acc[r.cls];
+        a.n++;
+        a.ms += ms;
+        a.flops += r.flops;
+        a.bytes += r.bytes;
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return GP_OK;
+}
+
+extern "C" int gp_timing_report(int cls, long* launches, double* ms, double* flops, double* bytes) {
+    if (cls < 0 || cls >= GP_KC_COUNT) return gp_fail(GP_ERR_INVALID, "bad kernel class %d", cls);
+    *launches = g_acc[cls].n;
+    *ms = g_acc[cls].ms;
+    *flops = g_acc[cls].flops;
+    *bytes = g_acc[cls].bytes;
+    return GP_OK;
+}

@@ -1,0 +1,264 @@
+"""Thin tensor->pointer marshalling over the C ABI (include/givepose_hip.h).
+
+Every function launches hand-written HIP kernels from libgivepose_hip.so on torch's current HIP
+stream, writes into caller-provided (or freshly torch.empty'd) buffers and never falls back to a
+PyTorch implementation: a missing library raises at import of the first op.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_RELU,
+                   EPI_SCALE_RES, GP_F16, GP_F32, GemmDesc, check)
+
+__all__ = ["dtype_code", "gemm", "conv2d_nhwc", "dcnv3_forward", "dcnv3_forward_into", "convnext_stem", "dwconv_ln",
+           "layernorm", "groupnorm", "upsample_bilinear2x", "deconv_col2im", "xyz_out_layer", "pointwise_k3",
+           "pnp_conv1", "xyz_conv3x3_s2", "size_head", "pose_tail", "mask_resize_nearest"]
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt):
+    if dt == torch.float16:
+        return GP_F16
+    if dt == torch.float32:
+        return GP_F32
+    raise TypeError(f"unsupported dtype {dt} (float16 / float32)")
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # dcnv3_cuda.cu:32-34
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _contig(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")  # dcnv3_cuda.cu:29-31
+    return t
+
+
+# ----------------------------------------------------------------------------------- GEMM / conv
+_WS = {}
+
+
+def _workspace(device, nfloats):
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < nfloats:
+        if ws is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-K workspace too small during graph capture")
+        ws = torch.empty(max(nfloats, 1 << 24), dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
+
+
+def auto_splitk(M, N, K, esz, n_cu=256):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nkt = K // (128 // esz)
+    if tiles >= n_cu // 2 or nkt < 8:
+        return 1
+    return max(1, min(nkt // 4, (n_cu + tiles - 1) // tiles, 32))
+
+
+def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
+         ldres=None, conv=None, splitk=None):
+    """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
+    dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
+    dt = x.dtype
+    code = dtype_code(dt)
+    _chk(x, "x"), _chk(w, "w", dt), _chk(out, "out")
+    N = w.shape[0]
+    Kw = w.shape[1]
+    d = GemmDesc()
+    if conv is not None:
+        B, H, W_, Cin, KH, KW, stride, pad = (conv[k] for k in ("B", "H", "W", "Cin", "KH", "KW", "stride", "pad"))
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W_ + 2 * pad - KW) // stride + 1
+        M = B * Ho * Wo
+        K = KH * KW * Cin
+        d.B, d.H, d.Win, d.Cin, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = B, H, W_, Cin, KH, KW, stride, pad, Ho, Wo
+        ldx = 0
+    else:
+        M = x.shape[0] if M is None else M
+        K = Kw if K is None else K
+        ldx = x.stride(0) if ldx is None else ldx
+    assert K == Kw, (K, Kw)
+    out_f32 = 1 if (out.dtype == torch.float32 and dt != torch.float32) else 0
+    if out.dtype not in (dt, torch.float32):
+        raise TypeError("gemm: out dtype must equal x dtype or float32")
+    ldc = out.stride(0) if ldc is None else ldc
+    esz = 2 if code == GP_F16 else 4
+    if splitk is None:
+        splitk = auto_splitk(M, N, K, esz)
+    d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.gamma = gamma.data_ptr() if gamma is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    if splitk > 1:
+        d.workspace = _workspace(x.device, splitk * M * N).data_ptr()
+    d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
+    d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
+    d.epilogue, d.out_f32, d.splitk, d.dtype = epilogue, out_f32, splitk, code
+    check(_L().gp_gemm(ctypes.byref(d), _stream()), "gp_gemm")
+    return out
+
+
+def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE):
+    """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
+    B, H, W_, Cin = x.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W_ + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
+    gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
+         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad))
+    return out
+
+
+# ----------------------------------------------------------------------------------- DCNv3
+def dcnv3_forward_into(inp, offset, mask, out, K, stride, pad, dil, G, D, offset_scale, im2col_step=256,
+                       remove_center=0, off_ld=None, mask_ld=None, mask_is_logits=False):
+    _contig(_chk(inp, "input"), "input"), _chk(offset, "offset"), _chk(mask, "mask"), _contig(_chk(out, "out"), "out")
+    N, H, W_, C = inp.shape
+    P = K * K - int(remove_center)
+    if C != G * D:
+        raise RuntimeError(f"Input channels and group times group channels wont match: ({C} vs {G * D}).")
+    if offset.dtype != mask.dtype:
+        raise TypeError("offset and mask must share a dtype")
+    check(_L().gp_dcnv3_forward(_ptr(inp), _ptr(offset), _ptr(mask), _ptr(out), N, H, W_, G, D, K, stride, pad, dil,
+                                float(offset_scale), int(remove_center), int(im2col_step),
+                                G * P * 2 if off_ld is None else off_ld, G * P if mask_ld is None else mask_ld,
+                                1 if mask_is_logits else 0, dtype_code(inp.dtype), dtype_code(offset.dtype), _stream()),
+          "gp_dcnv3_forward")
+    return out
+
+
+def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                  group, group_channels, offset_scale, im2col_step, remove_center=0):
+    """Drop-in for the reference pybind op ``DCNv3.dcnv3_forward`` (network/ops_dcnv3/src/vision.cpp:15,
+    dcnv3.h:20-38; called from functions/dcnv3_func.py:53): same argument list, channels-last tensors, returns a
+    freshly allocated (N,Ho,Wo,G*D) tensor.  offset/mask are consumed as flat buffers exactly like the CUDA kernel."""
+    if not (kernel_h == kernel_w and stride_h == stride_w and pad_h == pad_w and dilation_h == dilation_w):
+        raise NotImplementedError("gp_dcnv3_forward supports square kernels / strides / pads / dilations")
+    _contig(offset, "offset"), _contig(mask, "mask")
+    N, H, W_, _ = input.shape
+    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
+    Wo = (W_ + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    need = N * Ho * Wo * group * (kernel_h * kernel_w - int(remove_center))
+    if offset.numel() < need * 2 or mask.numel() < need:
+        raise RuntimeError("offset/mask buffers smaller than the kernel consumes")
+    out = torch.empty(N, Ho, Wo, group * group_channels, dtype=input.dtype, device=input.device)
+    return dcnv3_forward_into(input, offset, mask, out, kernel_h, stride_h, pad_h, dilation_h, group, group_channels,
+                              offset_scale, im2col_step, remove_center)
+
+
+# ----------------------------------------------------------------------------------- norms & small ops
+def convnext_stem(img, w, b, ln_w, ln_b, out, eps=1e-6):
+    B, _, H, W_ = img.shape
+    _contig(_chk(img, "img", torch.float32), "img")
+    check(_L().gp_convnext_stem(_ptr(img), _ptr(w), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, w.shape[0],
+                                eps, dtype_code(out.dtype), _stream()), "gp_convnext_stem")
+    return out
+
+
+def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels=None):
+    B, H, W_, C = x.shape
+    n = B * H * W_ if n_pixels is None else n_pixels
+    check(_L().gp_dwconv_ln(_ptr(_contig(x, "x")), _ptr(wt), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, C, KS,
+                            eps, act, n, dtype_code(x.dtype), _stream()), "gp_dwconv_ln")
+    return out
+
+
+def layernorm(x, w, b, out, eps=1e-6):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, dtype_code(x.dtype), _stream()),
+          "gp_layernorm")
+    return out
+
+
+def groupnorm_chunks(HW):
+    return _L().gp_groupnorm_chunks(HW)
+
+
+def groupnorm(x, w, b, out, G, act, partial, stats, eps=1e-5, ldy=None):
+    """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed."""
+    B, HW, C = x.shape
+    code = dtype_code(x.dtype)
+    check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), _ptr(stats), B, HW, C, G, eps, code, _stream()),
+          "gp_groupnorm_stats")
+    check(_L().gp_groupnorm_apply(_ptr(x), _ptr(stats), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, act,
+                                  C if ldy is None else ldy, code, _stream()), "gp_groupnorm_apply")
+    return out
+
+
+def upsample_bilinear2x(x, out):
+    B, H, W_, C = x.shape
+    check(_L().gp_upsample_bilinear2x(_ptr(_contig(x, "x")), _ptr(out), B, H, W_, C, dtype_code(x.dtype), _stream()),
+          "gp_upsample_bilinear2x")
+    return out
+
+
+def deconv_col2im(cols, out, B, H, W_, C):
+    check(_L().gp_deconv_col2im(_ptr(cols), _ptr(out), B, H, W_, C, dtype_code(out.dtype), _stream()), "gp_deconv_col2im")
+    return out
+
+
+def xyz_out_layer(x, w, b, out_nchw, out_nhwc4):
+    B, HW, C = x.shape
+    check(_L().gp_xyz_out_layer(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C,
+                                dtype_code(x.dtype), _stream()), "gp_xyz_out_layer")
+
+
+def pointwise_k3(xyz4, w, b, out):
+    rows = xyz4.shape[0]
+    check(_L().gp_pointwise_k3(_ptr(xyz4), _ptr(w), _ptr(b), _ptr(out), rows, w.shape[0], dtype_code(out.dtype), _stream()),
+          "gp_pointwise_k3")
+    return out
+
+
+def pnp_conv1(xyz4, coord2d, w, out, B, R):
+    check(_L().gp_pnp_conv1(_ptr(xyz4), _ptr(_contig(coord2d, "coord2d")), _ptr(w), _ptr(out), B, R, w.shape[0],
+                            dtype_code(out.dtype), _stream()), "gp_pnp_conv1")
+    return out
+
+
+def xyz_conv3x3_s2(xyz4, w, out, B, R):
+    check(_L().gp_xyz_conv3x3_s2(_ptr(xyz4), _ptr(w), _ptr(out), B, R, w.shape[0], dtype_code(out.dtype), _stream()),
+          "gp_xyz_conv3x3_s2")
+    return out
+
+
+def size_head(feat, w1, b1, w2, b2, mean_size, out):
+    B, HW, C = feat.shape
+    check(_L().gp_size_head(_ptr(_contig(feat, "feat")), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mean_size), _ptr(out), B,
+                            HW, C, w1.shape[0], dtype_code(feat.dtype), _stream()), "gp_size_head")
+    return out
+
+
+def pose_tail(h, hz, ldh, W, cam_K, bbox_center, resize_ratio, roi_wh, wild6d, site, outs, B):
+    check(_L().gp_pose_tail(_ptr(h), _ptr(hz), ldh, _ptr(W["fc_r.w"]), _ptr(W["fc_r.b"]), _ptr(W["fc_t.w"]), _ptr(W["fc_t.b"]),
+                            _ptr(W["fc_z.w"]), _ptr(W["fc_z.b"]), _ptr(cam_K), _ptr(bbox_center), _ptr(resize_ratio),
+                            _ptr(roi_wh), int(wild6d), int(site), _ptr(outs["rot6d"]), _ptr(outs["pred_t"]),
+                            _ptr(outs["rot_allo"]), _ptr(outs["rot_ego"]), _ptr(outs["trans"]), B, _stream()), "gp_pose_tail")
+
+
+def mask_resize_nearest(mask, out):
+    B, _, S, _ = mask.shape
+    R = out.shape[-1]
+    check(_L().gp_mask_resize_nearest(_ptr(_contig(_chk(mask, "mask", torch.float32), "mask")), _ptr(out), B, S, R, _stream()),
+          "gp_mask_resize_nearest")
+    return out

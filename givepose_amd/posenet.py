@@ -1,0 +1,358 @@
+"""PoseNet on hand-written HIP kernels -- drop-in for the reference ``network.PoseNet.PoseNet``.
+
+Same public surface as the reference (network/PoseNet.py:134-231):
+  * ``PoseNet(cfg)``; ``forward(data, device, do_loss=False, pred_scale=None) -> dict`` with keys
+    ``rot`` (CPU fp32, as the reference returns it), ``trans``, ``size``, ``mask``, ``nocs_coor``,
+    ``ivfc_coor``;
+  * ``state_dict()`` / ``load_state_dict()`` use the reference's tensor names and shapes
+    (tests/golden/state_dict_manifest.json), including ConvModule's duplicated ``.norm``/``.gn`` keys and the
+    unused ``DCNv3_C.bn`` tensors, so ``evaluation/evaluate.py:51-56`` works unchanged.
+The arithmetic runs entirely in libgivepose_hip.so (givepose_amd/csrc); there is no PyTorch/CPU fallback.
+Everything is channels-last on the device; the whole launch sequence of one forward is optionally captured
+in a hipGraph and replayed (``use_graph=True``).
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops, synth
+from ._lib import (ACT_GELU, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_SCALE_RES)
+from .config import PoseNetConfig
+
+
+class _Node(nn.Module):
+    """Container mirroring one level of the reference module tree (names only)."""
+
+
+def _register(root, name, tensor, is_param):
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    if is_param:
+        mod.register_parameter(parts[-1], tensor)
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+_BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class PoseNet(nn.Module):
+    def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None):
+        super().__init__()
+        if cfg.main_backbone != "convnext":
+            raise NotImplementedError("reference PoseNet asserts backbone == 'convnext' (network/PoseNet.py:142)")
+        self.cfg = cfg
+        self.compute_dtype = dtype
+        self.use_graph = use_graph
+        self.ROT_TYPE, self.TRANS_TYPE, self.Z_TYPE = cfg.r_type, "centroid_z", "REL"
+        self.out_res = cfg.out_res
+        aliases = {}
+        for name, shape in synth.param_manifest(cfg).items():
+            is_buf = name.endswith(_BUFFER_SUFFIXES)
+            key = name.replace(".gn.", ".norm.")
+            if key in aliases and key != name:       # ConvModule: .gn is the same Parameter as .norm
+                t = aliases[key]
+            else:
+                if seed is None:
+                    val = torch.zeros(shape, dtype=torch.int64 if name.endswith("num_batches_tracked") else torch.float32)
+                else:
+                    val = torch.from_numpy(synth.synth_tensor(name, shape, seed))
+                t = val if is_buf else nn.Parameter(val, requires_grad=False)
+                aliases[key] = t
+            _register(self, name, t, not is_buf)
+        self._packed = None       # device-side packed weights
+        self._plans = {}          # B -> buffers / graph
+        self.eval()
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self._packed = None
+        self._plans = {}
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._packed = None
+        self._plans = {}
+        return r
+
+    @torch.no_grad()
+    def _pack(self, device):
+        """Reference-layout fp32 state dict -> kernel-layout device tensors (done once)."""
+        sd = {k: v.detach().to(device=device, dtype=torch.float32) if v.is_floating_point() else v
+              for k, v in self.state_dict().items()}
+        T = self.compute_dtype
+        f32 = lambda t: t.contiguous().float()
+        lowp = lambda t: t.contiguous().to(T)
+        W = {}
+        cfg = self.cfg
+        g = lambda k: sd["backbone." + k]
+        W["stem.w"], W["stem.b"] = f32(g("stem_0.weight")), f32(g("stem_0.bias"))
+        W["stem.ln_w"], W["stem.ln_b"] = f32(g("stem_1.weight")), f32(g("stem_1.bias"))
+        for s, (d, n) in enumerate(zip(cfg.convnext_dims, cfg.convnext_depths)):
+            if s > 0:
+                p = f"stages_{s}.downsample."
+                W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"] = f32(g(p + "0.weight")), f32(g(p + "0.bias"))
+                W[f"ds{s}.w"] = lowp(g(p + "1.weight").permute(0, 2, 3, 1).reshape(d, -1))
+                W[f"ds{s}.b"] = f32(g(p + "1.bias"))
+            for b in range(n):
+                p, q = f"stages_{s}.blocks.{b}.", f"s{s}b{b}."
+                W[q + "dw_w"] = f32(g(p + "conv_dw.weight").reshape(d, 49).t())
+                W[q + "dw_b"] = f32(g(p + "conv_dw.bias"))
+                W[q + "ln_w"], W[q + "ln_b"] = f32(g(p + "norm.weight")), f32(g(p + "norm.bias"))
+                W[q + "fc1_w"], W[q + "fc1_b"] = lowp(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
+                W[q + "fc2_w"], W[q + "fc2_b"] = lowp(g(p + "mlp.fc2.weight")), f32(g(p + "mlp.fc2.bias"))
+                W[q + "gamma"] = f32(g(p + "gamma"))
+        for head in ("xyz_nocs_head", "xyz_deform_head"):
+            h = lambda k: sd[f"{head}.{k}"]
+            W[head + ".deconv_w"] = lowp(h("features.0.weight").permute(2, 3, 1, 0).reshape(9 * 256, -1))
+            W[head + ".gn0_w"], W[head + ".gn0_b"] = f32(h("features.1.weight")), f32(h("features.1.bias"))
+            for i in (3, 4, 6, 7, 9, 10):
+                W[f"{head}.c{i}_w"] = lowp(h(f"features.{i}.conv.weight").permute(0, 2, 3, 1).reshape(256, -1))
+                W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"] = f32(h(f"features.{i}.norm.weight")), f32(h(f"features.{i}.norm.bias"))
+            W[head + ".out_w"], W[head + ".out_b"] = f32(h("out_layer.weight").reshape(3, 256)), f32(h("out_layer.bias"))
+        # SizeHead: fold eval BatchNorm1d into conv1 (pose_head.py:34-35)
+        sc = sd["size_head.bn1.weight"] / torch.sqrt(sd["size_head.bn1.running_var"] + 1e-5)
+        W["size.w1"] = f32(sd["size_head.conv1.weight"].squeeze(-1) * sc[:, None])
+        W["size.b1"] = f32((sd["size_head.conv1.bias"] - sd["size_head.bn1.running_mean"]) * sc + sd["size_head.bn1.bias"])
+        W["size.w2"], W["size.b2"] = f32(sd["size_head.conv2.weight"].squeeze(-1)), f32(sd["size_head.conv2.bias"])
+        for li, i in enumerate((0, 3, 6)):
+            p, q = f"nocs_encoder.features.{i}.", f"enc{li}."
+            if cfg.use_dcn == "dcnv3":
+                cw = sd[p + "conv.weight"].reshape(256, -1)
+                W[q + "conv_w"] = f32(cw) if li == 0 else lowp(cw)
+                W[q + "conv_b"] = f32(sd[p + "conv.bias"])
+                d = p + "dcnv3."
+                W[q + "dw_w"] = f32(sd[d + "dw_conv.0.weight"].reshape(256, 9).t())
+                W[q + "dw_b"] = f32(sd[d + "dw_conv.0.bias"])
+                W[q + "ln_w"], W[q + "ln_b"] = f32(sd[d + "dw_conv.1.1.weight"]), f32(sd[d + "dw_conv.1.1.bias"])
+                W[q + "om_w"] = lowp(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
+                W[q + "om_b"] = f32(torch.cat([sd[d + "offset.bias"], sd[d + "mask.bias"]], 0))
+                W[q + "in_w"], W[q + "in_b"] = lowp(sd[d + "input_proj.weight"]), f32(sd[d + "input_proj.bias"])
+                W[q + "out_w"], W[q + "out_b"] = lowp(sd[d + "output_proj.weight"]), f32(sd[d + "output_proj.bias"])
+            else:
+                cw = sd[p + "weight"]
+                W[q + "conv_w"] = f32(cw) if li == 0 else lowp(cw.permute(0, 2, 3, 1).reshape(256, -1))
+            W[q + "gn_w"], W[q + "gn_b"] = f32(sd[f"nocs_encoder.features.{i + 1}.weight"]), f32(sd[f"nocs_encoder.features.{i + 1}.bias"])
+        W["red.w"], W["red.b"] = lowp(sd["feat_reducer.weight"].reshape(256, -1)), f32(sd["feat_reducer.bias"])
+        W["pnp.c0_w"] = f32(sd["pnp_net.features.0.weight"])
+        for li, i in enumerate((0, 3, 6)):
+            if li > 0:
+                W[f"pnp.c{li}_w"] = lowp(sd[f"pnp_net.features.{i}.weight"].permute(0, 2, 3, 1).reshape(128, -1))
+            W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"] = f32(sd[f"pnp_net.features.{i + 1}.weight"]), f32(sd[f"pnp_net.features.{i + 1}.bias"])
+        # fc1 || fc1_z as one GEMM; columns permuted from the reference's NCHW flatten (c*64+hw,
+        # conv_pnp_net.py:170-172) to the channels-last flatten (hw*128+c) used on the device
+        perm = lambda w: w.reshape(-1, 128, 64).permute(0, 2, 1).reshape(-1, 8192)
+        W["pnp.fc1_w"] = lowp(torch.cat([perm(sd["pnp_net.fc1.weight"]), perm(sd["pnp_net.fc1_z.weight"])], 0))
+        W["pnp.fc1_b"] = f32(torch.cat([sd["pnp_net.fc1.bias"], sd["pnp_net.fc1_z.bias"]], 0))
+        W["pnp.fc2_w"], W["pnp.fc2_b"] = lowp(sd["pnp_net.fc2.weight"]), f32(sd["pnp_net.fc2.bias"])
+        W["pnp.fc2z_w"], W["pnp.fc2z_b"] = lowp(sd["pnp_net.fc2_z.weight"]), f32(sd["pnp_net.fc2_z.bias"])
+        for n in ("fc_r", "fc_t", "fc_z"):
+            W[n + ".w"], W[n + ".b"] = f32(sd[f"pnp_net.{n}.weight"]), f32(sd[f"pnp_net.{n}.bias"])
+        self._packed = W
+        return W
+
+    # ------------------------------------------------------------------ buffers
+    def _plan(self, B, device):
+        plan = self._plans.get(B)
+        if plan is not None:
+            return plan
+        T, cfg = self.compute_dtype, self.cfg
+        R, S = cfg.out_res, cfg.img_size
+        e = lambda *shape, dtype=T: torch.empty(*shape, dtype=dtype, device=device)
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)
+        buf = {}
+        # static inputs
+        buf["roi_img"], buf["roi_mask"] = f(B, 3, S, S), f(B, 1, S, S)
+        buf["roi_coord_2d"], buf["cam_K"], buf["roi_wh"] = f(B, 2, R, R), f(B, 3, 3), f(B, 2)
+        buf["bbox_center"], buf["resize_ratio"], buf["mean_size"] = f(B, 2), f(B), f(B, 3)
+        # trunk
+        dims = cfg.convnext_dims
+        H = S // 4
+        for s, d in enumerate(dims):
+            h = H >> s
+            buf[f"x{s}"] = e(B, h, h, d)
+            buf[f"t{s}"] = e(B, h, h, d)
+            buf[f"h{s}"] = e(B * h * h, 4 * d)
+            if s > 0:
+                buf[f"dsn{s}"] = e(B, h * 2, h * 2, dims[s - 1])
+        # heads
+        buf["cols"] = f(B * 64, 9 * 256)
+        for r in (16, 32, 64):
+            buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
+        chunks = ops.groupnorm_chunks(R * R)
+        buf["gn_partial"], buf["gn_stats"] = f(B * chunks * 32 * 2), f(B * 32 * 2)
+        buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
+        buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
+        buf["mask_out"], buf["size"] = f(B, 1, R, R), f(B, 3)
+        for li, r in enumerate((64, 32, 16)):
+            buf[f"e_in{li}"], buf[f"e_proj{li}"] = e(B, r, r, 256), e(B, r, r, 256)
+            buf[f"e_x1{li}"] = e(B * r * r // 4, 256)
+            buf[f"e_om{li}"] = f(B * r * r // 4, 108)
+            buf[f"e_g{li}"], buf[f"e_o{li}"] = e(B, r // 2, r // 2, 256), e(B, r // 2, r // 2, 256)
+        buf["feat_cat"] = e(B, 8, 8, 512)
+        buf["p0"], buf["p1"], buf["p2"] = e(B, 32, 32, 128), e(B, 16, 16, 128), e(B, 8, 8, 128)
+        buf["fc1"] = e(B, 2048)
+        buf["hh"], buf["hz"] = f(B, 256), f(B, 256)
+        buf["rot6d"], buf["pred_t"], buf["rot_allo"], buf["rot_ego"], buf["trans"] = f(B, 6), f(B, 3), f(B, 9), f(B, 9), f(B, 3)
+        plan = {"buf": buf, "graph": None, "warm": False}
+        self._plans[B] = plan
+        return plan
+
+    # ------------------------------------------------------------------ launch sequence
+    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None):
+        B = x.shape[0]
+        C = x.shape[-1]
+        xv = x.view(B, -1, C)
+        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], buf["gn_stats"], ldy=ldy)
+
+    def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
+        """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows."""
+        ops.gemm(feat2d, W[head + ".deconv_w"], buf["cols"])
+        y = ops.deconv_col2im(buf["cols"], buf["ya16"], B, 8, 8, 256)
+        self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
+        cur, r = y, 16
+        for i in (3, 4, 6, 7, 9, 10):
+            if i in (6, 9):
+                r *= 2
+                cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"])
+            dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
+            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst)
+            self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf)
+            cur = dst
+        ops.xyz_out_layer(cur.view(B, r * r, 256), W[head + ".out_w"], W[head + ".out_b"], out_nchw, out_nhwc4)
+
+    def _launch_all(self, B, plan):
+        W, buf, cfg = self._packed, plan["buf"], self.cfg
+        dims, depths = cfg.convnext_dims, cfg.convnext_depths
+        ops.mask_resize_nearest(buf["roi_mask"], buf["mask_out"])
+        # ---- ConvNeXt trunk (network/backbone.py:36-46)
+        x = ops.convnext_stem(buf["roi_img"], W["stem.w"], W["stem.b"], W["stem.ln_w"], W["stem.ln_b"], buf["x0"])
+        for s, (d, n) in enumerate(zip(dims, depths)):
+            if s > 0:
+                t = ops.layernorm(x, W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"], buf[f"dsn{s}"])
+                x = ops.conv2d_nhwc(t, W[f"ds{s}.w"], 2, 2, 2, 0, out=buf[f"x{s}"], bias=W[f"ds{s}.b"])
+            x2d = x.view(-1, d)
+            for b in range(n):
+                q = f"s{s}b{b}."
+                t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7)
+                ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU)
+                ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
+                         gamma=W[q + "gamma"], residual=x2d)
+        feat = x                                    # (B,8,8,1024)
+        fc = dims[-1]
+        feat2d = feat.view(B * 64, fc)
+        ops.size_head(feat.view(B, 64, fc), W["size.w1"], W["size.b1"], W["size.w2"], W["size.b2"], buf["mean_size"], buf["size"])
+        self._xyz_head(W, "xyz_nocs_head", feat2d, B, buf, buf["nocs_nchw"], buf["nocs_nhwc4"])
+        # ---- MAPEncoder (network/conv_pnp_net.py:303-332)
+        cat2d = buf["feat_cat"].view(B * 64, 512)
+        prev = None
+        for li, r in enumerate((64, 32, 16)):
+            q = f"enc{li}."
+            ro = r // 2
+            if cfg.use_dcn == "dcnv3":
+                xin = buf[f"e_in{li}"]
+                if li == 0:
+                    ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "conv_w"], W[q + "conv_b"], xin.view(-1, 256))
+                else:
+                    ops.gemm(prev.view(-1, 256), W[q + "conv_w"], xin.view(-1, 256), bias=W[q + "conv_b"])
+                ops.gemm(xin.view(-1, 256), W[q + "in_w"], buf[f"e_proj{li}"].view(-1, 256), bias=W[q + "in_b"])
+                nq = B * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
+                ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"e_x1{li}"], 3,
+                              act=ACT_GELU, n_pixels=nq)
+                om = ops.gemm(buf[f"e_x1{li}"], W[q + "om_w"], buf[f"e_om{li}"], bias=W[q + "om_b"])
+                ops.dcnv3_forward_into(buf[f"e_proj{li}"], om, om[:, 72:], buf[f"e_g{li}"], 3, 2, 1, 1, 4, 64, 1.0,
+                                       off_ld=108, mask_ld=108, mask_is_logits=True)
+                y = buf[f"e_o{li}"]
+                ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"])
+            else:
+                y = buf[f"e_o{li}"]
+                if li == 0:
+                    ops.xyz_conv3x3_s2(buf["nocs_nhwc4"], W[q + "conv_w"], y, B, r)
+                else:
+                    ops.conv2d_nhwc(prev, W[q + "conv_w"], 3, 3, 2, 1, out=y)
+            if li < 2:
+                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf)
+                prev = y
+            else:   # last layer normalises straight into the right half of feat_cat (PoseNet.py:193)
+                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf, out=cat2d[:, 256:], ldy=512)
+        ops.gemm(feat2d, W["red.w"], cat2d, bias=W["red.b"], ldc=512)
+        self._xyz_head(W, "xyz_deform_head", cat2d, B, buf, buf["ivfc_nchw"], buf["ivfc_nhwc4"])
+        # ---- ConvPnPNet (network/conv_pnp_net.py:137-201)
+        R = cfg.out_res
+        p = ops.pnp_conv1(buf["ivfc_nhwc4"], buf["roi_coord_2d"], W["pnp.c0_w"], buf["p0"], B, R)
+        self._gn(p, W["pnp.g0_w"], W["pnp.g0_b"], ACT_RELU, buf)
+        for li in (1, 2):
+            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"])
+            self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf)
+            p = nxt
+        ops.gemm(p.view(B, 8192), W["pnp.fc1_w"], buf["fc1"], bias=W["pnp.fc1_b"], epilogue=EPI_LRELU)
+        ops.gemm(buf["fc1"], W["pnp.fc2_w"], buf["hh"], bias=W["pnp.fc2_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048)
+        ops.gemm(buf["fc1"][:, 1024:], W["pnp.fc2z_w"], buf["hz"], bias=W["pnp.fc2z_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048)
+        ops.pose_tail(buf["hh"], buf["hz"], 256, W, buf["cam_K"], buf["bbox_center"], buf["resize_ratio"], buf["roi_wh"],
+                      cfg.dataset == "wild6d", cfg.t_type == "site", buf, B)
+
+    # ------------------------------------------------------------------ public API
+    _INPUT_KEYS = ("roi_img", "roi_mask", "roi_coord_2d", "cam_K", "roi_wh", "bbox_center", "resize_ratio", "mean_size")
+
+    @torch.no_grad()
+    def forward_device(self, data, device="cuda"):
+        """Runs the path and returns views of the static output buffers, all on the device (no D->H sync)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("givepose_amd.PoseNet runs on the HIP device only (no CPU path)")
+        _lib.load()
+        if self._packed is None:
+            self._pack(device)
+        B = data["roi_img"].shape[0]
+        plan = self._plan(B, device)
+        buf = plan["buf"]
+        for k in self._INPUT_KEYS:
+            src = data[k]
+            if src.data_ptr() != buf[k].data_ptr():
+                buf[k].copy_(src.reshape(buf[k].shape), non_blocking=True)
+        if self.use_graph and plan["warm"]:
+            if plan["graph"] is None:
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                lib = _lib.load()
+                _lib.check(lib.gp_graph_begin(stream), "gp_graph_begin")
+                try:
+                    self._launch_all(B, plan)
+                finally:
+                    ge = ctypes.c_void_p()
+                    rc = lib.gp_graph_end(stream, ctypes.byref(ge))
+                _lib.check(rc, "gp_graph_end")
+                plan["graph"] = ge
+            _lib.check(_lib.load().gp_graph_launch(plan["graph"], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "gp_graph_launch")
+        else:
+            self._launch_all(B, plan)
+            plan["warm"] = True
+        return {"rot": buf["rot_ego"].view(B, 3, 3), "trans": buf["trans"], "size": buf["size"], "mask": buf["mask_out"],
+                "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
+                "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf[f"x{len(self.cfg.convnext_dims) - 1}"],
+                "feat_cat": buf["feat_cat"]}
+
+    def static_inputs(self, B, device="cuda"):
+        """The plan's device-resident input buffers (fill these to skip the per-call H->D copies)."""
+        if self._packed is None:
+            self._pack(torch.device(device))
+        return {k: self._plan(B, torch.device(device))["buf"][k] for k in self._INPUT_KEYS}
+
+    @torch.no_grad()
+    def forward(self, data, device="cuda", do_loss=False, pred_scale=None):
+        """Reference signature (network/PoseNet.py:173).  ``do_loss`` (training) is out of scope."""
+        if do_loss:
+            raise NotImplementedError("training path (do_loss=True) is out of scope for the inference build")
+        out = self.forward_device(data, device)
+        # the reference returns rot as a CPU tensor (pose_from_pred_centroid_z.py:157) and fresh tensors
+        return {"rot": out["rot"].cpu(), "trans": out["trans"].clone(), "size": out["size"].clone(),
+                "mask": out["mask"].clone(), "nocs_coor": out["nocs_coor"].clone(), "ivfc_coor": out["ivfc_coor"].clone()}

@@ -1,0 +1,191 @@
+/* givepose_hip.h -- C ABI of libgivepose_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the GIVEPose PoseNet inference path.  The one
+ * native op of the reference on this path is the pybind module `DCNv3`
+ * (network/ops_dcnv3/src/vision.cpp:14-17, dcnv3.h:20-38): gp_dcnv3_forward replaces
+ * `dcnv3_forward`.  Every other entry point replaces an ATen/cuDNN call the reference makes from
+ * Python on this path; the replaced call site is cited on each.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless named host_*; the caller owns every buffer
+ *     (outputs are caller-allocated, no hidden allocation, no hidden synchronisation);
+ *   - activations are channels-last: (N, H, W, C) contiguous, C fastest;
+ *   - `dtype` is the storage type of activations and weights: GP_F32 or GP_F16; accumulation,
+ *     normalisation statistics, biases and norm affine parameters are always fp32;
+ *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous;
+ *   - return value 0 on success, negative gp_status otherwise (never printf-and-continue, unlike
+ *     dcnv3_im2col_cuda.cuh:913-916); gp_last_error() gives the message for the calling thread.
+ */
+#ifndef GIVEPOSE_HIP_H
+#define GIVEPOSE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum gp_status { GP_OK = 0, GP_ERR_INVALID = -1, GP_ERR_LAUNCH = -2, GP_ERR_RUNTIME = -3 };
+enum gp_dtype { GP_F32 = 0, GP_F16 = 1 };
+enum gp_act { GP_ACT_NONE = 0, GP_ACT_GELU = 1, GP_ACT_RELU = 2, GP_ACT_LRELU = 3 /* slope 0.1 */ };
+/* GEMM epilogues: v = acc + bias; then */
+enum gp_epilogue {
+    GP_EPI_NONE = 0,      /* out = v                                        */
+    GP_EPI_GELU = 1,      /* out = gelu_erf(v)                              */
+    GP_EPI_RELU = 2,      /* out = max(v, 0)                                */
+    GP_EPI_LRELU = 3,     /* out = v > 0 ? v : 0.1 v                        */
+    GP_EPI_SCALE_RES = 4  /* out = residual + gamma[n] * v  (ConvNeXt block) */
+};
+
+const char* gp_last_error(void);
+int gp_version(void);
+/* device properties the host needs: CU count and arch string ("gfx950...") */
+int gp_device_info(int* cu_count, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * DCNv3 forward -- replaces DCNv3.dcnv3_forward (network/ops_dcnv3/src/dcnv3.h:20-38 ->
+ * cuda/dcnv3_cuda.cu:21-85 -> cuda/dcnv3_im2col_cuda.cuh:216-282).
+ *   in   (N,H,W,G*D) dtype;  out (N,Ho,Wo,G*D) dtype, Ho = (H+2*pad-(dil*(K-1)+1))/stride+1.
+ *   offset / mask: FLAT buffers of om_dtype indexed exactly as the CUDA kernel does, i.e. row
+ *     r = (b*Ho+ho)*Wo+wo, element r*off_ld + (g*P+p)*2 + {0:w,1:h} and r*mask_ld + g*P+p, with
+ *     P = K*K - remove_center and taps ordered kernel_w outer / kernel_h inner.  With
+ *     off_ld = G*P*2 and mask_ld = G*P this is the reference addressing, including the stride-2
+ *     case where the buffers are (N,H,W,..)-shaped and only the flat prefix is consumed.
+ *   mask_is_logits != 0: `mask` holds pre-softmax logits and the kernel applies the softmax over
+ *     the P taps of each group (fuses modules/dcnv3.py:331-333 into the gather).
+ *   Requires batch <= im2col_step or batch % im2col_step == 0 like dcnv3_cuda.cu:46-49.
+ */
+int gp_dcnv3_forward(const void* in, const void* offset, const void* mask, void* out, int N, int H, int W,
+                     int G, int D, int K, int stride, int pad, int dil, float offset_scale,
+                     int remove_center, int im2col_step, int off_ld, int mask_ld, int mask_is_logits,
+                     int dtype, int om_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused GEMM / implicit-GEMM convolution on MFMA.
+ *   C[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] ),  m < M, n < N.
+ * Replaces F.linear / nn.Conv2d (1x1, 2x2 s2, 3x3 s1/s2) call sites: timm ConvNeXt pointwise
+ * MLPs + downsample convs (network/backbone.py:36-46), ConvModule convs
+ * (network/torch_utils/layers/conv_module.py:224-234), ConvPnPNet convs/fc
+ * (network/conv_pnp_net.py:164-199), DCNv3 Linear projections (ops_dcnv3/modules/dcnv3.py:325-354),
+ * feat_reducer (network/PoseNet.py:192), ConvTranspose2d as GEMM + gp_deconv_col2im.
+ *   W: (N, K) row-major, K fastest; for conv mode K index = (kh*KW + kw)*Cin + ci.
+ *   conv mode (KH > 0): X is (B,H,W,Cin) channels-last, M = B*Ho*Wo, zero padding `pad`;
+ *     requires Cin % (128/sizeof(dtype)) == 0.  plain mode (KH == 0): X is (M, K) with row stride ldx.
+ *   K % (128/sizeof(dtype)) == 0 and N % 4 == 0 required.
+ *   bias/gamma fp32 [N] (bias may be NULL); residual same dtype as X, row stride ldres.
+ *   out_f32 != 0 stores fp32 instead of dtype.  C row stride ldc (elements of the output type).
+ *   splitk > 1: K is cut in `splitk` slices; `workspace` must hold splitk*M*N floats.
+ */
+typedef struct gp_gemm_desc {
+    const void* X;
+    const void* W;
+    const float* bias;
+    const float* gamma;
+    const void* residual;
+    void* C;
+    float* workspace;
+    int M, N, K;
+    int ldx, ldc, ldres;
+    int epilogue;
+    int out_f32;
+    int splitk;
+    /* conv mode */
+    int B, H, Win, Cin, KH, KW, stride, pad, Ho, Wo;
+    int dtype;
+} gp_gemm_desc;
+int gp_gemm(const gp_gemm_desc* d, void* stream);
+
+/* ConvNeXt stem: conv4x4 s4 (3->C0, bias) + LayerNorm over channels (eps).  img is the
+ * reference's NCHW fp32 `roi_img` (network/PoseNet.py:174); out is (B,H/4,W/4,C0) channels-last.
+ * w is (C0,3,4,4) fp32 as stored in the checkpoint. C0 must be 128. */
+int gp_convnext_stem(const float* img, const float* w, const float* b, const float* ln_w, const float* ln_b,
+                     void* out, int B, int H, int W, int C0, float eps, int dtype, void* stream);
+
+/* depth-wise KSxKS conv (pad KS/2, stride 1, bias) + LayerNorm over C (+ optional GELU):
+ * ConvNeXt block front half (dw7x7 -> LN) and DCNv3's dw_conv branch (dw3x3 -> LN -> GELU,
+ * ops_dcnv3/modules/dcnv3.py:277-296).  wt: (KS*KS, C) fp32 tap-major.  Only the first
+ * `n_pixels` flat pixels (b,h,w order) are produced (DCNv3 consumes a prefix). */
+int gp_dwconv_ln(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+                 void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
+                 void* stream);
+
+/* row LayerNorm over C (ConvNeXt downsample LayerNorm2d). */
+int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,
+                 int dtype, void* stream);
+
+/* GroupNorm (nn.GroupNorm(G, C), eps) over channels-last x (B, HW, C):
+ *   gp_groupnorm_stats -> stats (B, G, 2) fp32 = (mean, rstd); partial is scratch of
+ *   B*chunks*G*2 floats where chunks = gp_groupnorm_chunks(HW).
+ *   gp_groupnorm_apply: y = act((x-mean)*rstd*w + b); y row stride ldy (concat targets). */
+int gp_groupnorm_chunks(int HW);
+int gp_groupnorm_stats(const void* x, float* partial, float* stats, int B, int HW, int C, int G, float eps,
+                       int dtype, void* stream);
+int gp_groupnorm_apply(const void* x, const float* stats, const float* w, const float* b, void* y, int B,
+                       int HW, int C, int G, int act, int ldy, int dtype, void* stream);
+
+/* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), channels-last (xyz_head.py:264). */
+int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+
+/* ConvTranspose2d(k3,s2,p1,op1,bias=False) second half: cols (B*H*W, 9*C) fp32 from gp_gemm with
+ * W[(kh*3+kw)*C + co][ci] -> out (B,2H,2W,C) dtype (xyz_head.py:250-259). */
+int gp_deconv_col2im(const float* cols, void* out, int B, int H, int W, int C, int dtype, void* stream);
+
+/* xyz out layer: Conv2d(C,3,1)+bias (xyz_head.py:317-324).  Writes the reference-layout NCHW fp32 map
+ * (B,3,HW) and a channels-last (B*HW, 4) fp32 copy (x,y,z,0) for the next consumer. */
+int gp_xyz_out_layer(const void* x, const float* w, const float* b, float* out_nchw, float* out_nhwc4,
+                     int B, int HW, int C, int dtype, void* stream);
+
+/* Conv2d(3, Cout, 1)+bias on the (B*HW,4) fp32 coordinate map (DCNv3_C.conv of the first MAPEncoder
+ * layer, network/dcnv3.py:26,33). w (Cout,3) fp32. */
+int gp_pointwise_k3(const float* xyz4, const float* w, const float* b, void* y, long rows, int Cout,
+                    int dtype, void* stream);
+
+/* ConvPnPNet first conv: Conv2d(5,Cout,3,s2,p1,bias=False) on cat(ivfc (B*HW,4) fp32, roi_coord_2d
+ * (B,2,R,R) fp32 NCHW) (network/PoseNet.py:196-197, conv_pnp_net.py:72-83). w (Cout,5,3,3) fp32.
+ * out (B,R/2,R/2,Cout) dtype. */
+int gp_pnp_conv1(const float* xyz4, const float* coord2d, const float* w, void* y, int B, int R, int Cout,
+                 int dtype, void* stream);
+
+/* Plain Conv2d(3,Cout,3,s2,p1,bias=False) on the (B*HW,4) fp32 coordinate map: first MAPEncoder layer
+ * when use_dcn='' (conv_pnp_net.py:258-272). w (Cout,3,3,3) fp32. */
+int gp_xyz_conv3x3_s2(const float* xyz4, const float* w, void* y, int B, int R, int Cout, int dtype,
+                      void* stream);
+
+/* SizeHead (network/pose_head.py:30-42) + mean-size residual (network/PoseNet.py:199-202):
+ * feat (B,HW,C); w1 (F,C) / b1 (F) with eval BatchNorm folded in; w2 (3,F), b2 (3);
+ * out size (B,3) fp32 = head + mean_size/||mean_size||. */
+int gp_size_head(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
+                 const float* mean_size, float* size, int B, int HW, int C, int F, int dtype, void* stream);
+
+/* Pose tail: fc_r/fc_t/fc_z (conv_pnp_net.py:190-199), rot6d -> R (pose_utils/rot_reps.py:34-55),
+ * centroid/z back-projection and allocentric -> egocentric (pose_from_pred_centroid_z.py:60-157,
+ * pose_utils/utils.py:29-84) on device.  h / hz: (B,256) fp32 rows with stride ldh.
+ * outputs fp32: rot6d (B,6), pred_t (B,3), rot_allo (B,9), rot_ego (B,9), trans (B,3). */
+int gp_pose_tail(const float* h, const float* hz, int ldh, const float* w_r, const float* b_r,
+                 const float* w_t, const float* b_t, const float* w_z, const float* b_z, const float* cam_K,
+                 const float* bbox_center, const float* resize_ratio, const float* roi_wh, int wild6d,
+                 int site_centroid, float* rot6d, float* pred_t, float* rot_allo, float* rot_ego,
+                 float* trans, int B, void* stream);
+
+/* torchvision Resize(out, NEAREST) on a square fp32 mask (B,1,S,S) -> (B,1,R,R) (PoseNet.py:170,180). */
+int gp_mask_resize_nearest(const float* mask, float* out, int B, int S, int R, void* stream);
+
+/* ---- hipGraph capture of a launch sequence (launch-bound inner loop -> one graph launch) */
+int gp_graph_begin(void* stream);
+int gp_graph_end(void* stream, void** graph_exec_out);
+int gp_graph_launch(void* graph_exec, void* stream);
+int gp_graph_destroy(void* graph_exec);
+
+/* ---- per-launch HIP-event timing (bench.py roofline leg).  Between begin/end every gp_* launch on
+ * `stream` is bracketed by hipEvents; gp_timing_report fills, per kernel class (GP_KC_*), launches,
+ * total ms, algorithmic flops and bytes. */
+enum gp_kernel_class {
+    GP_KC_GEMM = 0, GP_KC_DCNV3 = 1, GP_KC_DWCONV_LN = 2, GP_KC_NORM = 3, GP_KC_ELEMENTWISE = 4,
+    GP_KC_SMALL = 5, GP_KC_COUNT = 6
+};
+int gp_timing_begin(void* stream);
+int gp_timing_end(void);
+int gp_timing_report(int cls, long* launches, double* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

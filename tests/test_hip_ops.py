@@ -1,0 +1,354 @@
+"""GPU parity tests, op level: every C-ABI entry point of libgivepose_hip.so against a plain PyTorch fp32
+CPU reference of the same op (DCNv3: the oracle restatement of the reference CUDA kernel + golden vectors).
+
+Tolerances: fp32 storage path 2e-5 relative-to-scale (fp32 MFMA/accumulate, summation order differs);
+fp16 storage path 4e-3 relative-to-scale (fp16 rounding of inputs/outputs, fp32 accumulate).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.float16]
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3}
+
+
+def ops():
+    from givepose_amd import ops as o
+    return o
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def q(t, dt):
+    """Round a fp32 CPU tensor to the storage dtype (so the reference sees the same inputs)."""
+    return t.to(dt).float()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 108, 256), (64, 2048, 1024), (4096, 256, 512), (37, 12, 64)])
+def test_gemm_plain(dt, M, N, K):
+    o = ops()
+    x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=K ** -0.5), dt), rnd(N, seed=3)
+    ref = x @ w.t() + b
+    out = torch.empty(M, N, dtype=dt, device="cuda")
+    o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda())
+    assert rel_err(out, ref) < TOL[dt]
+    out32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    o.gemm(x.to("cuda", dt), w.to("cuda", dt), out32, bias=b.cuda())
+    assert rel_err(out32, ref) < 2e-5 * (4 if dt == torch.float16 else 1) + (0 if dt == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("splitk", [1, 4, 7])
+def test_gemm_splitk_and_epilogues(dt, splitk):
+    o = ops()
+    M, N, K = 64, 256, 2048
+    x, w, b = q(rnd(M, K, seed=4), dt), q(rnd(N, K, seed=5, scale=K ** -0.5), dt), rnd(N, seed=6)
+    res, gamma = q(rnd(M, N, seed=7), dt), rnd(N, seed=8)
+    lin = x @ w.t() + b
+    cases = {o.EPI_GELU: F.gelu(lin), o.EPI_RELU: F.relu(lin), o.EPI_LRELU: F.leaky_relu(lin, 0.1),
+             o.EPI_SCALE_RES: res + gamma * lin}
+    for epi, ref in cases.items():
+        out = torch.empty(M, N, dtype=dt, device="cuda")
+        kw = dict(gamma=gamma.cuda(), residual=res.to("cuda", dt)) if epi == o.EPI_SCALE_RES else {}
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda(), epilogue=epi, splitk=splitk, **kw)
+        assert rel_err(out, ref) < TOL[dt], epi
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_strided_views(dt):
+    """ldx (column slice of a wider matrix) and ldc (write into a concat buffer)."""
+    o = ops()
+    M, K, N = 96, 128, 64
+    xw = q(rnd(M, 2 * K, seed=9), dt)
+    w = q(rnd(N, K, seed=10, scale=K ** -0.5), dt)
+    ref = xw[:, K:] @ w.t()
+    big = torch.zeros(M, 3 * N, dtype=dt, device="cuda")
+    xd = xw.to("cuda", dt)
+    o.gemm(xd[:, K:], w.to("cuda", dt), big[:, N:2 * N], M=M, K=K, ldx=2 * K, ldc=3 * N)
+    assert rel_err(big[:, N:2 * N], ref) < TOL[dt]
+    assert float(big[:, :N].abs().max()) == 0 and float(big[:, 2 * N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [dict(B=2, H=16, Cin=128, Cout=256, k=3, s=1, p=1), dict(B=3, H=16, Cin=64, Cout=128, k=3, s=2, p=1),
+                                 dict(B=2, H=8, Cin=128, Cout=256, k=2, s=2, p=0), dict(B=1, H=8, Cin=64, Cout=64, k=1, s=1, p=0)])
+def test_conv_implicit_gemm(dt, cfg):
+    o = ops()
+    B, H, Cin, Cout, k, s, p = (cfg[n] for n in ("B", "H", "Cin", "Cout", "k", "s", "p"))
+    x = q(rnd(B, Cin, H, H, seed=11), dt)
+    w = q(rnd(Cout, Cin, k, k, seed=12, scale=(Cin * k * k) ** -0.5), dt)
+    b = rnd(Cout, seed=13)
+    ref = F.conv2d(x, w, b, stride=s, padding=p).permute(0, 2, 3, 1)
+    xp = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", dt)
+    out = o.conv2d_nhwc(xp, wp, k, k, s, p, bias=b.cuda())
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL[dt]
+
+
+def test_gemm_rejects_bad_shapes():
+    o = ops()
+    from givepose_amd._lib import GivePoseHipError
+    x = torch.zeros(8, 100, device="cuda")
+    w = torch.zeros(8, 100, device="cuda")
+    with pytest.raises(GivePoseHipError):
+        o.gemm(x, w, torch.empty(8, 8, device="cuda"))      # K not a multiple of 32
+
+
+# ----------------------------------------------------------------------------------------------- DCNv3
+@pytest.mark.parametrize("name", ["dcnv3_s1", "dcnv3_s2_B1", "dcnv3_s2_B4", "dcnv3_s2_B5"])
+def test_dcnv3_golden_fp32(golden, name):
+    """Drop-in op (reference pybind signature) against vectors produced by the reference itself."""
+    o = ops()
+    z = golden(name)
+    K, s, p, d, G, D, rc = (int(v) for v in z["params"])
+    cu = lambda a: torch.from_numpy(a).cuda()
+    out = o.dcnv3_forward(cu(z["input"]), cu(z["offset"]), cu(z["mask"]), K, K, s, s, p, p, d, d, G, D, float(z["offset_scale"]), 256, rc)
+    assert tuple(out.shape) == z["expected"].shape
+    assert np.abs(out.cpu().numpy() - z["expected"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rc", [0, 1])
+def test_dcnv3_vs_oracle(dt, rc):
+    from oracle.posenet_ref import dcnv3_forward_ref
+    o = ops()
+    N, H, G, D, K = 3, 12, 4, 64, 3
+    P = K * K - rc
+    x = q(rnd(N, H, H, G * D, seed=20), dt)
+    off = q(rnd(N, H, H, G * P * 2, seed=21, scale=2.0), dt)
+    m = torch.softmax(rnd(N, H, H, G, P, seed=22), -1).reshape(N, H, H, G * P)
+    m = q(m, dt)
+    for stride in (1, 2):
+        ref = dcnv3_forward_ref(x, off, m, K, stride, 1, 1, G, D, 1.0, rc)
+        out = o.dcnv3_forward(x.to("cuda", dt), off.to("cuda", dt), m.to("cuda", dt), K, K, stride, stride, 1, 1, 1, 1, G, D, 1.0, 256, rc)
+        assert rel_err(out, ref) < (1e-5 if dt == torch.float32 else 2e-3)
+
+
+def test_dcnv3_fused_softmax_and_strided_om():
+    """mask logits + fp32 offset/mask rows of a single (rows,108) GEMM output, as PoseNet uses the op."""
+    from oracle.posenet_ref import dcnv3_forward_ref
+    o = ops()
+    N, H, G, D, K, P = 4, 16, 4, 64, 3, 9
+    Ho = H // 2
+    x = rnd(N, H, H, 256, seed=23)
+    om = rnd(N * Ho * Ho, 108, seed=24, scale=1.5)
+    off, logits = om[:, :72], om[:, 72:]
+    mask = torch.softmax(logits.reshape(-1, G, P), -1).reshape(-1, G * P)
+    ref = dcnv3_forward_ref(x, off.contiguous(), mask.contiguous(), K, 2, 1, 1, G, D, 1.0, 0)
+    for dt in DT:
+        out = torch.empty(N, Ho, Ho, 256, dtype=dt, device="cuda")
+        omd = om.cuda()
+        o.dcnv3_forward_into(x.to("cuda", dt), omd, omd[:, 72:], out, K, 2, 1, 1, G, D, 1.0, off_ld=108, mask_ld=108, mask_is_logits=True)
+        refq = dcnv3_forward_ref(q(x, dt), off.contiguous(), mask.contiguous(), K, 2, 1, 1, G, D, 1.0, 0)
+        assert rel_err(out, refq) < (1e-5 if dt == torch.float32 else 2e-3)
+    assert ref.shape == (N, Ho, Ho, 256)
+
+
+def test_dcnv3_generic_geometry_and_errors():
+    from oracle.posenet_ref import dcnv3_forward_ref
+    from givepose_amd._lib import GivePoseHipError
+    o = ops()
+    N, H, G, D, K = 2, 9, 3, 8, 5       # odd sizes, G*D != 256 -> generic kernel
+    x, off = rnd(N, H, H, G * D, seed=25), rnd(N, H, H, G * K * K * 2, seed=26, scale=1.5)
+    m = torch.rand(N, H, H, G * K * K, generator=torch.Generator().manual_seed(27))
+    ref = dcnv3_forward_ref(x, off, m, K, 1, 2, 1, G, D, 1.5, 0)
+    out = o.dcnv3_forward(x.cuda(), off.cuda(), m.cuda(), K, K, 1, 1, 2, 2, 1, 1, G, D, 1.5, 256, 0)
+    assert rel_err(out, ref) < 1e-5
+    with pytest.raises(RuntimeError):      # reference: AT_ASSERTM contiguous (dcnv3_cuda.cu:29-31)
+        o.dcnv3_forward(x.cuda().permute(0, 2, 1, 3), off.cuda(), m.cuda(), K, K, 1, 1, 2, 2, 1, 1, G, D, 1.5, 256, 0)
+    with pytest.raises(RuntimeError):      # reference: CUDA tensors only (dcnv3_cuda.cu:32-34)
+        o.dcnv3_forward(x, off.cuda(), m.cuda(), K, K, 1, 1, 2, 2, 1, 1, G, D, 1.5, 256, 0)
+    with pytest.raises(GivePoseHipError):  # reference: batch % im2col_step (dcnv3_cuda.cu:46-49)
+        x3 = torch.zeros(3, 4, 4, 8, device="cuda")
+        o.dcnv3_forward(x3, torch.zeros(3, 4, 4, 18, device="cuda"), torch.zeros(3, 4, 4, 9, device="cuda"), 3, 3, 1, 1, 1, 1, 1, 1, 1, 8, 1.0, 2, 0)
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C,H,KS", [(128, 16, 7), (512, 8, 7), (1024, 8, 7), (256, 16, 3)])
+def test_dwconv_ln(dt, C, H, KS):
+    o = ops()
+    B = 2
+    x = q(rnd(B, C, H, H, seed=30), dt)
+    w, b = rnd(C, 1, KS, KS, seed=31, scale=1.0 / KS), rnd(C, seed=32, scale=0.1)
+    lw, lb = 1 + 0.1 * rnd(C, seed=33), 0.1 * rnd(C, seed=34)
+    y = F.conv2d(x, w, b, padding=KS // 2, groups=C).permute(0, 2, 3, 1)
+    ref = F.layer_norm(y, (C,), lw, lb, 1e-6)
+    act = o.ACT_GELU if KS == 3 else o.ACT_NONE
+    if KS == 3:
+        ref = F.gelu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    out = torch.zeros(B, H, H, C, dtype=dt, device="cuda")
+    o.dwconv_ln(xd, w.reshape(C, KS * KS).t().contiguous().cuda(), b.cuda(), lw.cuda(), lb.cuda(), out, KS, act=act)
+    assert rel_err(out, ref) < TOL[dt]
+    # prefix mode (DCNv3 consumes only the first quarter of the full-resolution grid)
+    n = B * H * H // 4
+    out2 = torch.full((B * H * H, C), 7.0, dtype=dt, device="cuda")
+    o.dwconv_ln(xd, w.reshape(C, KS * KS).t().contiguous().cuda(), b.cuda(), lw.cuda(), lb.cuda(), out2, KS, act=act, n_pixels=n)
+    assert rel_err(out2[:n], ref.reshape(-1, C)[:n]) < TOL[dt]
+    assert float((out2[n:] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [128, 256, 512])
+def test_layernorm(dt, C):
+    o = ops()
+    x = q(rnd(300, C, seed=35) * 2 + 0.5, dt)
+    lw, lb = 1 + 0.1 * rnd(C, seed=36), 0.1 * rnd(C, seed=37)
+    out = torch.empty(300, C, dtype=dt, device="cuda")
+    o.layernorm(x.to("cuda", dt), lw.cuda(), lb.cuda(), out)
+    assert rel_err(out, F.layer_norm(x, (C,), lw, lb, 1e-6)) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C,HW,act", [(256, 1024, "gelu"), (256, 256, "relu"), (128, 64, "relu"), (256, 64, "gelu")])
+def test_groupnorm(dt, C, HW, act):
+    o = ops()
+    B = 3
+    x = q(rnd(B, C, HW, seed=38) * 1.5 + 0.3, dt)
+    gw, gb = 1 + 0.1 * rnd(C, seed=39), 0.1 * rnd(C, seed=40)
+    ref = F.group_norm(x, 32, gw, gb, 1e-5)
+    ref = (F.gelu(ref) if act == "gelu" else F.relu(ref)).permute(0, 2, 1)
+    xd = x.permute(0, 2, 1).contiguous().to("cuda", dt)
+    partial = torch.empty(B * o.groupnorm_chunks(HW) * 64, device="cuda")
+    stats = torch.empty(B * 64, device="cuda")
+    wide = torch.zeros(B, HW, 2 * C, dtype=dt, device="cuda")
+    o.groupnorm(xd, gw.cuda(), gb.cuda(), wide[:, :, C:], 32, o.ACT_GELU if act == "gelu" else o.ACT_RELU, partial, stats, ldy=2 * C)
+    assert rel_err(wide[:, :, C:], ref) < TOL[dt]
+    assert float(wide[:, :, :C].abs().max()) == 0.0
+    o.groupnorm(xd, gw.cuda(), gb.cuda(), xd, 32, o.ACT_GELU if act == "gelu" else o.ACT_RELU, partial, stats)   # in place
+    assert rel_err(xd, ref) < TOL[dt]
+
+
+# ----------------------------------------------------------------------------------------------- small ops
+@pytest.mark.parametrize("dt", DT)
+def test_stem(dt):
+    o = ops()
+    B = 2
+    img = rnd(B, 3, 64, 128, seed=41)
+    w, b = rnd(128, 3, 4, 4, seed=42, scale=48 ** -0.5), rnd(128, seed=43, scale=0.1)
+    lw, lb = 1 + 0.1 * rnd(128, seed=44), 0.1 * rnd(128, seed=45)
+    ref = F.layer_norm(F.conv2d(img, w, b, stride=4).permute(0, 2, 3, 1), (128,), lw, lb, 1e-6)
+    out = torch.empty(B, 16, 32, 128, dtype=dt, device="cuda")
+    o.convnext_stem(img.cuda(), w.cuda(), b.cuda(), lw.cuda(), lb.cuda(), out)
+    assert rel_err(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_upsample_and_col2im(dt):
+    o = ops()
+    B, H, C = 2, 8, 256
+    x = q(rnd(B, C, H, H, seed=46), dt)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    out = torch.empty(B, 2 * H, 2 * H, C, dtype=dt, device="cuda")
+    o.upsample_bilinear2x(x.permute(0, 2, 3, 1).contiguous().to("cuda", dt), out)
+    assert rel_err(out, ref) < TOL[dt]
+    # ConvTranspose2d(k3,s2,p1,op1) = GEMM + col2im
+    Cin = 128
+    xi = q(rnd(B, Cin, H, H, seed=47), dt)
+    wt = q(rnd(Cin, C, 3, 3, seed=48, scale=(Cin * 9 / 4) ** -0.5), dt)
+    ref = F.conv_transpose2d(xi, wt, None, stride=2, padding=1, output_padding=1).permute(0, 2, 3, 1)
+    cols = torch.empty(B * H * H, 9 * C, dtype=torch.float32, device="cuda")
+    o.gemm(xi.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to("cuda", dt), wt.permute(2, 3, 1, 0).reshape(9 * C, Cin).contiguous().to("cuda", dt), cols)
+    out = torch.empty(B, 2 * H, 2 * H, C, dtype=dt, device="cuda")
+    o.deconv_col2im(cols, out, B, H, H, C)
+    assert rel_err(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_xyz_out_pointwise_smallcin(dt):
+    o = ops()
+    B, R, C = 2, 16, 256
+    x = q(rnd(B, R * R, C, seed=49), dt)
+    w, b = rnd(3, C, seed=50, scale=C ** -0.5), rnd(3, seed=51)
+    ref = x @ w.t() + b                                           # (B, HW, 3)
+    nchw, nhwc4 = torch.empty(B, 3, R, R, device="cuda"), torch.empty(B * R * R, 4, device="cuda")
+    o.xyz_out_layer(x.to("cuda", dt), w.cuda(), b.cuda(), nchw, nhwc4)
+    assert rel_err(nchw.reshape(B, 3, -1).permute(0, 2, 1), ref) < 2e-5
+    assert rel_err(nhwc4.reshape(B, -1, 4)[..., :3], ref) < 2e-5 and float(nhwc4[:, 3].abs().max()) == 0
+    xyz = nhwc4.cpu()
+    w3, b3 = rnd(256, 3, seed=52), rnd(256, seed=53)
+    out = torch.empty(B * R * R, 256, dtype=dt, device="cuda")
+    o.pointwise_k3(nhwc4, w3.cuda(), b3.cuda(), out)
+    assert rel_err(out, xyz[:, :3] @ w3.t() + b3) < TOL[dt]
+    # tiny-Cin 3x3 s2 convs
+    coord = rnd(B, 2, R, R, seed=54)
+    xin = torch.cat([xyz[:, :3].reshape(B, R, R, 3).permute(0, 3, 1, 2), coord], 1)
+    w5 = rnd(128, 5, 3, 3, seed=55, scale=45 ** -0.5)
+    out5 = torch.empty(B, R // 2, R // 2, 128, dtype=dt, device="cuda")
+    o.pnp_conv1(nhwc4, coord.cuda(), w5.cuda(), out5, B, R)
+    assert rel_err(out5, F.conv2d(xin, w5, None, stride=2, padding=1).permute(0, 2, 3, 1)) < TOL[dt]
+    w3c = rnd(256, 3, 3, 3, seed=56, scale=27 ** -0.5)
+    out3 = torch.empty(B, R // 2, R // 2, 256, dtype=dt, device="cuda")
+    o.xyz_conv3x3_s2(nhwc4, w3c.cuda(), out3, B, R)
+    assert rel_err(out3, F.conv2d(xin[:, :3], w3c, None, stride=2, padding=1).permute(0, 2, 3, 1)) < TOL[dt]
+
+
+def test_size_head_golden(golden):
+    """vs the reference SizeHead output (BN folded on the host) + mean-size residual."""
+    from givepose_amd import synth
+    o = ops()
+    z = golden("size_head")
+    sd = {k: torch.from_numpy(synth.synth_tensor("size_head." + k, s, 0)) for k, s in
+          (("conv1.weight", (128, 1024, 1)), ("conv1.bias", (128,)), ("conv2.weight", (3, 128, 1)), ("conv2.bias", (3,)),
+           ("bn1.weight", (128,)), ("bn1.bias", (128,)), ("bn1.running_mean", (128,)), ("bn1.running_var", (128,)))}
+    sc = sd["bn1.weight"] / torch.sqrt(sd["bn1.running_var"] + 1e-5)
+    w1 = (sd["conv1.weight"].squeeze(-1) * sc[:, None]).contiguous()
+    b1 = (sd["conv1.bias"] - sd["bn1.running_mean"]) * sc + sd["bn1.bias"]
+    x = torch.from_numpy(z["x"])
+    B = x.shape[0]
+    ms = torch.tensor([[0.1, 0.2, 0.3]] * B)
+    out = torch.empty(B, 3, device="cuda")
+    o.size_head(x.permute(0, 2, 3, 1).reshape(B, 64, 1024).contiguous().cuda(), w1.cuda(), b1.cuda(),
+                sd["conv2.weight"].squeeze(-1).contiguous().cuda(), sd["conv2.bias"].cuda(), ms.cuda(), out)
+    ref = torch.from_numpy(z["expected"]) + ms / ms.norm(dim=1, keepdim=True)
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("ds", ["CAMERA_Real", "wild6d"])
+def test_pose_tail_golden(golden, ds):
+    """fc_r/fc_t/fc_z + rot6d + allo->ego decode on device vs the reference's numpy/transforms3d path."""
+    o = ops()
+    z = golden("pose_decode_" + ds)
+    B = z["d6"].shape[0]
+    # feed identity-like heads so the tail's fc outputs equal the golden d6 / pred_t
+    h = torch.zeros(B, 256)
+    hz = torch.zeros(B, 256)
+    h[:, :6] = torch.from_numpy(z["d6"])
+    h[:, 6:8] = torch.from_numpy(z["pred_t"][:, :2])
+    hz[:, 0] = torch.from_numpy(z["pred_t"][:, 2])
+    wr, wt_, wz = torch.zeros(6, 256), torch.zeros(2, 256), torch.zeros(1, 256)
+    for i in range(6):
+        wr[i, i] = 1
+    wt_[0, 6] = wt_[1, 7] = 1
+    wz[0, 0] = 1
+    W = {"fc_r.w": wr.cuda(), "fc_r.b": torch.zeros(6).cuda(), "fc_t.w": wt_.cuda(), "fc_t.b": torch.zeros(2).cuda(),
+         "fc_z.w": wz.cuda(), "fc_z.b": torch.zeros(1).cuda()}
+    outs = {k: torch.empty(B, n, device="cuda") for k, n in (("rot6d", 6), ("pred_t", 3), ("rot_allo", 9), ("rot_ego", 9), ("trans", 3))}
+    cu = lambda k: torch.from_numpy(z[k]).cuda()
+    o.pose_tail(h.cuda(), hz.cuda(), 256, W, cu("cam_K"), cu("bbox_center"), cu("resize_ratio"), cu("roi_wh"), ds == "wild6d", True, outs, B)
+    assert np.abs(outs["rot_allo"].cpu().numpy().reshape(B, 3, 3) - z["rot_allo"]).max() < 2e-6
+    assert np.abs(outs["rot_ego"].cpu().numpy().reshape(B, 3, 3) - z["rot"]).max() < 2e-6
+    assert np.abs(outs["trans"].cpu().numpy() - z["trans"]).max() < 1e-5 * max(1.0, np.abs(z["trans"]).max())
+
+
+def test_mask_resize_bit_exact():
+    o = ops()
+    m = (torch.rand(3, 1, 256, 256, generator=torch.Generator().manual_seed(60)) > 0.5).float()
+    out = torch.empty(3, 1, 64, 64, device="cuda")
+    o.mask_resize_nearest(m.cuda(), out)
+    assert torch.equal(out.cpu(), m[..., ::4, ::4])
