@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of PoseNet.forward on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path (ConvNeXt-B trunk, SizeHead, NOCS head, DCNv3 MAPEncoder, IVFC head,
+ConvPnPNet, pose decode) over one batch of 64 synthetic 256x256 crops per GPU, inputs resident in HBM, fp16
+storage / fp32 accumulate, random-init (seeded) weights; for N > 1 each rank owns its own 64 crops (weak
+scaling) and the step ends with the RCCL all-gather of the per-crop (R,t,s).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- dominant kernel (MFMA GEMM / implicit-GEMM conv): algorithmic FLOP per launch / average launch
+                  duration, measured with hipEvents around every launch of a separate eager pass on the launch
+                  stream (hipGraph replay of the timed region cannot carry per-kernel events); kernel_classes has
+                  the same for every kernel class, incl. the DCNv3 gather against the HBM roofline.
+  cpu_baseline -- the oracle (oracle/posenet_ref.py, fp32 PyTorch-CPU restatement of the reference) timed on this
+                  box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_CROP = {"full": 67.517, "nodcn": 66.506}
+GATHER_MB_PER_CROP = 3.74
+PEAK_F16_TFLOPS = 2500.0                                 # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--workload", default="full", choices=["full", "nodcn"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from givepose_amd import PoseNet, PoseNetConfig, _lib, synth
+    from givepose_amd import dist as gd
+    import torch.distributed as dist
+
+    rank, local, world = gd.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = args.batch
+    dtype = torch.float16 if args.dtype == "f16" else torch.float32
+    cfg = PoseNetConfig(use_dcn="dcnv3" if args.workload == "full" else "")
+    net = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph).to(dev)
+    static = net.static_inputs(B, dev)
+    host = synth.synth_batch(B, seed=1000 + rank)
+    for k, v in host.items():
+        static[k].copy_(torch.from_numpy(v).reshape(static[k].shape))
+    poses = torch.empty(B, gd.POSE_WIDTH, device=dev)
+    gathered = torch.empty(world * B, gd.POSE_WIDTH, device=dev) if world > 1 else None
+
+    def step():
+        out = net.forward_device(static, dev)
+        if world > 1:
+            gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses)
+            gd.all_gather_poses(poses, world, out=gathered)
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 2)):      # first call eager (+ graph capture on the second)
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    line = {
+        "metric": "images/sec PoseNet fwd, bs=64 256x256 fp16, 1/2/4/8 MI355X; % MFMA roofline",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("PoseNet.forward: ConvNeXt-B trunk + SizeHead + NOCS TopDownXyzHead + "
+                                + ("DCNv3 MAPEncoder" if args.workload == "full" else "plain-conv MAPEncoder (use_dcn='')")
+                                + " + IVFC TopDownXyzHead + ConvPnPNet + pose decode (BASELINE configs[2]; the reference wires "
+                                  "ConvNeXt-B, not ResNet-34: SURVEY.md 0.2)"),
+                   "batch_per_gpu": B, "global_batch": world * B, "img": "256x256", "parallelism": f"dp{world}",
+                   "weights": "seeded random init (givepose_amd.synth, seed 0)", "hipgraph": not args.no_graph,
+                   "collective": "all_gather (B,15) fp32 per rank" if world > 1 else "none"},
+        "path_roofline_frac_mfma": round(value / world * GFLOP_PER_CROP[args.workload] * 1e9 / (PEAK_F16_TFLOPS * 1e12), 4),
+    }
+
+    # ---------------- roofline leg: per-launch hipEvents on the launch stream, eager pass
+    if rank == 0 and not args.no_roofline:
+        lib = _lib.load()
+        net_e = net
+        net_e.use_graph = False
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        reps = 3
+        net_e.forward_device(static, dev)
+        torch.cuda.synchronize(dev)
+        _lib.check(lib.gp_timing_begin(stream), "gp_timing_begin")
+        for _ in range(reps):
+            net_e.forward_device(static, dev)
+        _lib.check(lib.gp_timing_end(), "gp_timing_end")
+        classes = {}
+        for c, name in enumerate(_lib.KC_NAMES):
+            n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            lib.gp_timing_report(c, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                classes[name] = {"launches_per_step": n.value // reps, "ms_per_step": round(ms.value / reps, 4),
+                                 "avg_launch_us": round(ms.value / n.value * 1e3, 2),
+                                 "tflops": round(fl.value / ms.value / 1e9, 2), "gbs": round(by.value / ms.value / 1e6, 1)}
+        g = classes["gemm"]
+        peak = PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3
+        line["roofline"] = {"kernel": "gemm_kernel<f16> (MFMA GEMM + implicit-GEMM conv, all launches of a step)",
+                            "bound": "mfma", "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
+                            "frac": round(g["tflops"] / peak, 4), "traffic": None,
+                            "launches_per_step": g["launches_per_step"], "avg_launch_us": g["avg_launch_us"]}
+        if "dcnv3" in classes:
+            d = classes["dcnv3"]
+            line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
+                                       "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None}
+        line["kernel_classes"] = classes
+        line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
+
+    # ---------------- CPU baseline: oracle on the host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import posenet_ref as O
+        P = O.load_params(synth.synth_state_dict(cfg, 0))
+        nb = 4
+        sample = {k: torch.from_numpy(v) for k, v in synth.synth_batch(nb, seed=1000).items()}
+        torch.set_num_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            O.posenet_forward_ref(P, sample, cfg)
+            n_it, t0 = 0, time.perf_counter()
+            while True:
+                O.posenet_forward_ref(P, sample, cfg)
+                n_it += 1
+                if time.perf_counter() - t0 > 12.0 or n_it >= 20:
+                    break
+            cdt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(nb * n_it / cdt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+                                "kind": "port", "sample": f"{n_it} x batch of {nb} crops, fp32 PyTorch-CPU oracle (oracle/posenet_ref.py)"}
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

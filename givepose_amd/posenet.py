@@ -69,6 +69,7 @@ class PoseNet(nn.Module):
             _register(self, name, t, not is_buf)
         self._packed = None       # device-side packed weights
         self._plans = {}          # B -> buffers / graph
+        self._stream = None       # dedicated stream of the hipGraph path
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -315,27 +316,38 @@ class PoseNet(nn.Module):
         B = data["roi_img"].shape[0]
         plan = self._plan(B, device)
         buf = plan["buf"]
-        for k in self._INPUT_KEYS:
-            src = data[k]
-            if src.data_ptr() != buf[k].data_ptr():
-                buf[k].copy_(src.reshape(buf[k].shape), non_blocking=True)
-        if self.use_graph and plan["warm"]:
-            if plan["graph"] is None:
-                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-                lib = _lib.load()
-                _lib.check(lib.gp_graph_begin(stream), "gp_graph_begin")
-                try:
-                    self._launch_all(B, plan)
-                finally:
-                    ge = ctypes.c_void_p()
-                    rc = lib.gp_graph_end(stream, ctypes.byref(ge))
-                _lib.check(rc, "gp_graph_end")
-                plan["graph"] = ge
-            _lib.check(_lib.load().gp_graph_launch(plan["graph"], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                       "gp_graph_launch")
+        cur = torch.cuda.current_stream()
+        if self.use_graph:
+            # hipGraph capture is not permitted on the legacy default stream: the graph path owns a stream
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=device)
+            self._stream.wait_stream(cur)
+            run_stream = self._stream
         else:
-            self._launch_all(B, plan)
-            plan["warm"] = True
+            run_stream = cur
+        with torch.cuda.stream(run_stream):
+            for k in self._INPUT_KEYS:
+                src = data[k]
+                if src.data_ptr() != buf[k].data_ptr():
+                    buf[k].copy_(src.reshape(buf[k].shape), non_blocking=True)
+            if self.use_graph and plan["warm"]:
+                lib = _lib.load()
+                sp = ctypes.c_void_p(run_stream.cuda_stream)
+                if plan["graph"] is None:
+                    _lib.check(lib.gp_graph_begin(sp), "gp_graph_begin")
+                    try:
+                        self._launch_all(B, plan)
+                    finally:
+                        ge = ctypes.c_void_p()
+                        rc = lib.gp_graph_end(sp, ctypes.byref(ge))
+                    _lib.check(rc, "gp_graph_end")
+                    plan["graph"] = ge
+                _lib.check(lib.gp_graph_launch(plan["graph"], sp), "gp_graph_launch")
+            else:
+                self._launch_all(B, plan)
+                plan["warm"] = True
+        if run_stream is not cur:
+            cur.wait_stream(run_stream)
         return {"rot": buf["rot_ego"].view(B, 3, 3), "trans": buf["trans"], "size": buf["size"], "mask": buf["mask_out"],
                 "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
                 "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf[f"x{len(self.cfg.convnext_dims) - 1}"],

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: shard bounds + all-gather of per-crop poses reproduce global crop order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from givepose_amd import dist as gd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, _, w = gd.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    full = {"rot": torch.randn(n_items, 3, 3, generator=g), "trans": torch.randn(n_items, 3, generator=g),
+            "size": torch.randn(n_items, 3, generator=g)}
+    mine = gd.shard_batch(full, r, w)
+    local = gd.pack_poses(mine["rot"], mine["trans"], mine["size"])
+    allp = gd.all_gather_poses(local, w)
+    R, t, s = gd.unpack_poses(allp)
+    ok = torch.equal(R, full["rot"]) and torch.equal(t, full["trans"]) and torch.equal(s, full["size"])
+    q.put((rank, ok, tuple(allp.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [8, 7])   # equal shards -> fused gather; ragged -> padded list gather
+def test_all_gather_poses_world2(n_items):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(60) for p in ps]
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (n_items, 15) for _, _, shape in res)
+
+
+def test_shard_bounds_cover_and_order():
+    for n in (0, 1, 5, 64, 513):
+        for w in (1, 2, 3, 8):
+            b = [gd.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
