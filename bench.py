@@ -148,9 +148,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import posenet_ref as O
         P = O.load_params(synth.synth_state_dict(cfg, 0))
-        nb = 4
+        nb = 2
         sample = {k: torch.from_numpy(v) for k, v in synth.synth_batch(nb, seed=1000).items()}
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))   # oversubscribing >32 threads slows the small ops down
         with torch.no_grad():
             O.posenet_forward_ref(P, sample, cfg)
             n_it, t0 = 0, time.perf_counter()

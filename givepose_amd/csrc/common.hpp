@@ -63,7 +63,21 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7) on v_rcp_f32 / v_exp_f32: ~16 VALU
+// instructions instead of the ~150 of libm's branchy erff, which made the GELU epilogue of the ConvNeXt
+// fc1 GEMMs VALU-bound (profiles/r01a).
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {

@@ -8,71 +8,55 @@ __device__ __forceinline__ void store_T(half_t* p, float v) { *p = (half_t)v; }
 __device__ __forceinline__ void store_T(float* p, float v) { *p = v; }
 
 // ------------------------------------------------------------------------------------- stem
-// conv4x4 s4 (3 -> 128) + LayerNorm over the 128 channels.  Block = 16 output pixels of one row.
+// conv4x4 s4 (3 -> 128) + LayerNorm over the 128 channels.  Block = PXB output pixels of one row; a wave owns
+// PXB/4 pixels and its 64 lanes own the 64 channel pairs of a pixel, so the LayerNorm reduction is a pure
+// wave butterfly.  The 48 x 2 filter taps of a lane's channel pair live in registers; the input patch rows are
+// staged once in LDS and read back as broadcast 16-B vectors (one (c,kh) row of 4 taps per read).
 template <typename T>
-__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wt,
                                                    const float* __restrict__ bias, const float* __restrict__ lnw,
                                                    const float* __restrict__ lnb, T* __restrict__ out, int H,
-                                                   int W, float eps) {
-    constexpr int C0 = 128, PXB = 16;
-    __shared__ float w_s[48][C0];
-    __shared__ float in_s[12][PXB * 4];
-    __shared__ float r2[4][8];
+                                                   int W, float eps, int PXB) {
+    constexpr int C0 = 128;
+    __shared__ __attribute__((aligned(16))) float in_s[12][256];
     const int Ho = H / 4, Wo = W / 4;
-    const int tid = threadIdx.x;
-    const int wblk = blockIdx.x % (Wo / PXB);
-    const int ho = (blockIdx.x / (Wo / PXB)) % Ho;
-    const int b = blockIdx.x / ((Wo / PXB) * Ho);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwb = Wo / PXB;
+    const int wblk = blockIdx.x % nwb;
+    const int ho = (blockIdx.x / nwb) % Ho;
+    const int b = blockIdx.x / (nwb * Ho);
     const int wo0 = wblk * PXB;
-    for (int i = tid; i < 48 * C0; i += 256) {  // w is (C0, 48) row-major -> transpose
-        const int co = i / 48, k = i - co * 48;
-        w_s[k][co] = w[i];
-    }
     for (int i = tid; i < 12 * PXB * 4; i += 256) {
         const int row = i / (PXB * 4), col = i - row * (PXB * 4);
         const int c = row >> 2, kh = row & 3;
         in_s[row][col] = img[(((long)b * 3 + c) * H + (ho * 4 + kh)) * W + wo0 * 4 + col];
     }
+    float2 wr[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) wr[k] = *reinterpret_cast<const float2*>(wt + k * C0 + lane * 2);
+    const float2 bv = *reinterpret_cast<const float2*>(bias + lane * 2);
+    const float2 gw = *reinterpret_cast<const float2*>(lnw + lane * 2), gb = *reinterpret_cast<const float2*>(lnb + lane * 2);
     __syncthreads();
-    const int ch = tid & 127, ph = tid >> 7;
-    float acc[8];
-    const float bv = bias[ch];
+    const int ppw = PXB / 4;
+    for (int q = 0; q < ppw; ++q) {
+        const int p = wave * ppw + q;
+        float a0 = bv.x, a1 = bv.y;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) acc[p] = bv;
-    for (int k = 0; k < 48; ++k) {
-        const float wv = w_s[k][ch];
-        const int row = k >> 2, kw = k & 3;
+        for (int row = 0; row < 12; ++row) {
+            const f32x4 iv = *reinterpret_cast<const f32x4*>(&in_s[row][p * 4]);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) acc[p] += in_s[row][(ph * 8 + p) * 4 + kw] * wv;
-    }
-    // LayerNorm across 128 channels = 2 waves per pixel half
-    const int wave = tid >> 6, lane = tid & 63;
-    float s[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) s[p] = group_sum(acc[p], 64);
-    if (lane == 0)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) r2[wave][p] = s[p];
-    __syncthreads();
-    float mean[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) mean[p] = (r2[ph * 2][p] + r2[ph * 2 + 1][p]) * (1.0f / C0);
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        acc[p] -= mean[p];
-        s[p] = group_sum(acc[p] * acc[p], 64);
-    }
-    if (lane == 0)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) r2[wave][p] = s[p];
-    __syncthreads();
-    const float gw = lnw[ch], gb = lnb[ch];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float var = (r2[ph * 2][p] + r2[ph * 2 + 1][p]) * (1.0f / C0);
-        const float v = acc[p] * rsqrtf(var + eps) * gw + gb;
-        store_T(out + ((((long)b * Ho + ho) * Wo + wo0 + ph * 8 + p) * C0 + ch), v);
+            for (int j = 0; j < 4; ++j) {
+                a0 = fmaf(iv[j], wr[row * 4 + j].x, a0);
+                a1 = fmaf(iv[j], wr[row * 4 + j].y, a1);
+            }
+        }
+        const float mean = group_sum(a0 + a1, 64) * (1.0f / C0);
+        a0 -= mean;
+        a1 -= mean;
+        const float rstd = rsqrtf(group_sum(a0 * a0 + a1 * a1, 64) * (1.0f / C0) + eps);
+        T* o = out + (((long)b * Ho + ho) * Wo + wo0 + p) * C0 + lane * 2;
+        store_T(o, a0 * rstd * gw.x + gb.x);
+        store_T(o + 1, a1 * rstd * gw.y + gb.y);
     }
 }
 
@@ -196,87 +180,94 @@ __global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------- tiny-Cin 3x3 s2 conv
 // input channels: c < 3 from xyz4 (B*R*R, 4); c in {3,4} from coord2d (B,2,R,R) when CIN == 5.
+// wt: (CIN*9, Cout) fp32, k = ci*9 + kh*3 + kw.  Block = 64 output pixels, filter bank staged once in LDS.
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __restrict__ xyz4,
                                                                 const float* __restrict__ coord2d,
-                                                                const float* __restrict__ w, T* __restrict__ y,
+                                                                const float* __restrict__ wt, T* __restrict__ y,
                                                                 int B, int R, int Cout) {
-    constexpr int KK = CIN * 9;
-    extern __shared__ float w_s[];  // [KK][Cout]
-    for (int i = threadIdx.x; i < KK * Cout; i += 256) {
-        const int co = i / KK, k = i - co * KK;  // w is (Cout, CIN, 3, 3) row-major
-        w_s[k * Cout + co] = w[i];
-    }
+    constexpr int KK = CIN * 9, PIXB = 64;
+    extern __shared__ __attribute__((aligned(16))) float w_s[];  // [KK][Cout]
+    for (int i = threadIdx.x; i < KK * Cout; i += 256) w_s[i] = wt[i];
     __syncthreads();
     const int Ro = R / 2, CQ = Cout / 4, PB = 256 / CQ;
     const int cq = threadIdx.x % CQ;
-    const long pix = (long)blockIdx.x * PB + threadIdx.x / CQ;
-    if (pix >= (long)B * Ro * Ro) return;
-    const int wo = (int)(pix % Ro);
-    const long t = pix / Ro;
-    const int ho = (int)(t % Ro);
-    const long b = t / Ro;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * 2 - 1 + kh;
-        if ((unsigned)hi >= (unsigned)R) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int wi = wo * 2 - 1 + kw;
-            if ((unsigned)wi >= (unsigned)R) continue;
-            const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + hi) * R + wi) * 4);
-            float in[CIN];
-            in[0] = p[0]; in[1] = p[1]; in[2] = p[2];
-            if constexpr (CIN == 5) {
-                in[3] = coord2d[((b * 2 + 0) * R + hi) * R + wi];
-                in[4] = coord2d[((b * 2 + 1) * R + hi) * R + wi];
-            }
+    const long npix = (long)B * Ro * Ro;
+    for (int it = threadIdx.x / CQ; it < PIXB; it += PB) {
+        const long pix = (long)blockIdx.x * PIXB + it;
+        if (pix >= npix) break;
+        const int wo = (int)(pix % Ro);
+        const long t = pix / Ro;
+        const int ho = (int)(t % Ro);
+        const long b = t / Ro;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if ((unsigned)hi >= (unsigned)R) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if ((unsigned)wi >= (unsigned)R) continue;
+                const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + hi) * R + wi) * 4);
+                float in[CIN];
+                in[0] = p[0]; in[1] = p[1]; in[2] = p[2];
+                if constexpr (CIN == 5) {
+                    in[3] = coord2d[((b * 2 + 0) * R + hi) * R + wi];
+                    in[4] = coord2d[((b * 2 + 1) * R + hi) * R + wi];
+                }
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + (c * 9 + kh * 3 + kw) * Cout + cq * 4);
+                for (int c = 0; c < CIN; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + (c * 9 + kh * 3 + kw) * Cout + cq * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += in[c] * wv[e];
+                    for (int e = 0; e < 4; ++e) acc[e] += in[c] * wv[e];
+                }
             }
         }
-    }
-    T* o = y + pix * Cout + cq * 4;
+        T* o = y + pix * Cout + cq * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) store_T(o + e, acc[e]);
+        for (int e = 0; e < 4; ++e) store_T(o + e, acc[e]);
+    }
 }
 
 // ------------------------------------------------------------------------------------- SizeHead
+// kernel 1: grid (B, F/16): global max over HW -> LDS, then 16 hidden units (BN folded, ReLU) -> scratch (B,F)
 template <typename T>
-__global__ __launch_bounds__(256) void size_head_kernel(const T* __restrict__ feat, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2,
-                                                        const float* __restrict__ mean_size, float* __restrict__ size,
-                                                        int HW, int C, int F) {
-    extern __shared__ float sh[];  // [C] pooled + [F] hidden
-    float* pooled = sh;
-    float* hid = sh + C;
+__global__ __launch_bounds__(256) void size_hidden_kernel(const T* __restrict__ feat, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, float* __restrict__ hid,
+                                                          int HW, int C, int F) {
+    extern __shared__ float pooled[];  // [C]
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        float m = -INFINITY;
-        for (int p = 0; p < HW; ++p) m = fmaxf(m, (float)feat[((long)b * HW + p) * C + c]);
-        pooled[c] = m;
+    for (int c4 = tid; c4 < C / 4; c4 += 256) {
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const T* p = feat + (long)b * HW * C + c4 * 4;
+        for (int px = 0; px < HW; ++px)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], (float)p[(long)px * C + e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pooled[c4 * 4 + e] = m[e];
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
-    for (int f = wave; f < F; f += 4) {
+    for (int j = 0; j < 4; ++j) {
+        const int f = blockIdx.y * 16 + wave * 4 + j;
+        if (f >= F) break;
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a += pooled[c] * w1[(long)f * C + c];
         a = group_sum(a, 64);
-        if (lane == 0) hid[f] = fmaxf(a + b1[f], 0.f);
+        if (lane == 0) hid[(long)b * F + f] = fmaxf(a + b1[f], 0.f);
     }
-    __syncthreads();
-    if (wave == 0) {
-        float ms[3] = {mean_size[b * 3], mean_size[b * 3 + 1], mean_size[b * 3 + 2]};
-        const float nrm = sqrtf(ms[0] * ms[0] + ms[1] * ms[1] + ms[2] * ms[2]);
-        for (int o = 0; o < 3; ++o) {
-            float a = 0.f;
-            for (int f = lane; f < F; f += 64) a += hid[f] * w2[o * F + f];
-            a = group_sum(a, 64);
-            if (lane == 0) size[b * 3 + o] = a + b2[o] + ms[o] / nrm;
-        }
+}
+
+__global__ __launch_bounds__(64) void size_out_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, const float* __restrict__ mean_size,
+                                                      float* __restrict__ size, int F) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float ms[3] = {mean_size[b * 3], mean_size[b * 3 + 1], mean_size[b * 3 + 2]};
+    const float nrm = sqrtf(ms[0] * ms[0] + ms[1] * ms[1] + ms[2] * ms[2]);
+    for (int o = 0; o < 3; ++o) {
+        float a = 0.f;
+        for (int f = lane; f < F; f += 64) a += hid[(long)b * F + f] * w2[o * F + f];
+        a = group_sum(a, 64);
+        if (lane == 0) size[b * 3 + o] = a + b2[o] + ms[o] / nrm;
     }
 }
 
@@ -374,12 +365,13 @@ extern "C" int gp_convnext_stem(const float* img, const float* w, const float* b
     GP_DT_OK(dtype);
     GP_REQUIRE(C0 == 128, "gp_convnext_stem: C0=%d unsupported (128)", C0);
     GP_REQUIRE(H % 4 == 0 && W % 64 == 0, "gp_convnext_stem: H,W=%d,%d must be multiples of 4,64", H, W);
+    const int PXB = (W / 4) % 64 == 0 ? 64 : 16;
     hipStream_t s = (hipStream_t)stream;
     const long px = (long)B * (H / 4) * (W / 4);
     gp_timing_before(s, GP_KC_SMALL, 2.0 * px * 48 * C0, (double)B * 3 * H * W * 4 + (double)px * C0 * (dtype == GP_F16 ? 2 : 4));
-    dim3 grid(B * (H / 4) * (W / 4 / 16));
-    if (dtype == GP_F16) hipLaunchKernelGGL(stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
-    else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (float*)out, H, W, eps);
+    dim3 grid(B * (H / 4) * (W / 4 / PXB));
+    if (dtype == GP_F16) hipLaunchKernelGGL(stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps, PXB);
+    else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (float*)out, H, W, eps, PXB);
     GP_LAUNCH_CHECK("gp_convnext_stem");
 }
 
@@ -445,13 +437,12 @@ static int launch_smallcin(const float* xyz4, const float* coord2d, const float*
     GP_REQUIRE(Cout % 4 == 0 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0, "%s: Cout=%d", name, Cout);
     hipStream_t s = (hipStream_t)stream;
     const long pix = (long)B * (R / 2) * (R / 2);
-    const int PB = 256 / (Cout / 4);
-    const size_t lds = (size_t)CIN * 9 * Cout * sizeof(float);
+        const size_t lds = (size_t)CIN * 9 * Cout * sizeof(float);
     gp_timing_before(s, GP_KC_SMALL, 2.0 * pix * CIN * 9 * Cout, (double)B * R * R * CIN * 4 + (double)pix * Cout * (dtype == GP_F16 ? 2 : 4));
     if (dtype == GP_F16)
-        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix, PB)), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix, 64)), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
     else
-        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix, PB)), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix, 64)), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
     GP_LAUNCH_CHECK(name);
 }
 
@@ -467,15 +458,17 @@ extern "C" int gp_xyz_conv3x3_s2(const float* xyz4, const float* w, void* y, int
 }
 
 extern "C" int gp_size_head(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
-                            const float* mean_size, float* size, int B, int HW, int C, int F, int dtype,
-                            void* stream) {
-    GP_REQUIRE(feat && w1 && b1 && w2 && b2 && mean_size && size && B > 0, "gp_size_head: bad argument");
+                            const float* mean_size, float* size, float* scratch, int B, int HW, int C, int F,
+                            int dtype, void* stream) {
+    GP_REQUIRE(feat && w1 && b1 && w2 && b2 && mean_size && size && scratch && B > 0, "gp_size_head: bad argument");
     GP_DT_OK(dtype);
+    GP_REQUIRE(C % 4 == 0 && F % 16 == 0, "gp_size_head: C=%d F=%d", C, F);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_SMALL, 2.0 * B * (C * F + 3 * F), (double)B * HW * C * (dtype == GP_F16 ? 2 : 4));
-    const size_t lds = (size_t)(C + F) * sizeof(float);
-    if (dtype == GP_F16) hipLaunchKernelGGL(size_head_kernel<half_t>, dim3(B), dim3(256), lds, s, (const half_t*)feat, w1, b1, w2, b2, mean_size, size, HW, C, F);
-    else hipLaunchKernelGGL(size_head_kernel<float>, dim3(B), dim3(256), lds, s, (const float*)feat, w1, b1, w2, b2, mean_size, size, HW, C, F);
+    const size_t lds = (size_t)C * sizeof(float);
+    if (dtype == GP_F16) hipLaunchKernelGGL(size_hidden_kernel<half_t>, dim3(B, F / 16), dim3(256), lds, s, (const half_t*)feat, w1, b1, scratch, HW, C, F);
+    else hipLaunchKernelGGL(size_hidden_kernel<float>, dim3(B, F / 16), dim3(256), lds, s, (const float*)feat, w1, b1, scratch, HW, C, F);
+    hipLaunchKernelGGL(size_out_kernel, dim3(B), dim3(64), 0, s, scratch, w2, b2, mean_size, size, F);
     GP_LAUNCH_CHECK("gp_size_head");
 }
 

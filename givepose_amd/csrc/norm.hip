@@ -45,12 +45,12 @@ template <> __device__ __forceinline__ void load_f32<float>(const float* p, floa
 
 // ---------------------------------------------------------------------------- dwconv + LN (+act)
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ wt,
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const T* __restrict__ wt,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, T* __restrict__ y, int H,
                                                         int W, int C, float eps, int act, long n_pixels) {
-    constexpr int VEC = Vec16<T>::N, PPT = 4, R = KS / 2;
+    constexpr int VEC = Vec16<T>::N, PPT = 8, R = KS / 2;
     __shared__ float red[4 * PPT];
     const int CT = C / VEC, PG = 256 / CT;
     const int cs = threadIdx.x % CT, pg = threadIdx.x / CT;
@@ -83,12 +83,11 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
             }
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
-                float wv[VEC];
-                load_f32<T>(wt + (long)(kh * KS + kw) * C + cs * VEC, wv);
+                const Vec16<T> wv = load16<T>(wt + (long)(kh * KS + kw) * C + cs * VEC);
 #pragma unroll
                 for (int p = 0; p < PPT; ++p)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[p][e] += in[p + kw].get(e) * wv[e];
+                    for (int e = 0; e < VEC; ++e) acc[p][e] += in[p + kw].get(e) * wv.get(e);
             }
         }
     }
@@ -225,32 +224,30 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int BG, int G,
-                                   int chunks, float inv_count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BG) return;
-    const int b = i / G, g = i - b * G;
-    double a = 0.0, q = 0.0;
-    for (int c = 0; c < chunks; ++c) {
-        const float* p = partial + (((long)b * chunks + c) * G + g) * 2;
-        a += p[0];
-        q += p[1];
-    }
-    const double mean = a * inv_count;
-    double var = q * inv_count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
                                                        const float* __restrict__ w, const float* __restrict__ bb,
-                                                       T* __restrict__ y, int HW, int C, int G, int act, int ldy) {
+                                                       T* __restrict__ y, int HW, int C, int G, int act, int ldy,
+                                                       int chunks, float inv_count, float eps) {
     constexpr int VEC = Vec16<T>::N;
+    __shared__ float st[256][2];
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
     const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
     const int b = blockIdx.y;
+    if (threadIdx.x < G) {  // finalize (mean, rstd) of group threadIdx.x from the chunk partials, fixed order
+        double a = 0.0, q = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = partial + (((long)b * chunks + c) * G + threadIdx.x) * 2;
+            a += p[0];
+            q += p[1];
+        }
+        const double mean = a * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[threadIdx.x][0] = (float)mean;
+        st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
     const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
     float sc[VEC], sh[VEC];
     {
@@ -260,9 +257,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const int g = (cs * VEC + e) / cpg;
-            const float mean = stats[((long)b * G + g) * 2], rstd = stats[((long)b * G + g) * 2 + 1];
-            sc[e] = rstd * gw[e];
-            sh[e] = gb[e] - mean * sc[e];
+            sc[e] = st[g][1] * gw[e];
+            sh[e] = gb[e] - st[g][0] * sc[e];
         }
     }
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
@@ -285,7 +281,7 @@ bool ct_ok(int C, int esz) {
 
 }  // namespace
 
-extern "C" int gp_dwconv_ln(const void* x, const float* wt, const float* bias, const float* ln_w,
+extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w,
                             const float* ln_b, void* y, int B, int H, int W, int C, int KS, float eps, int act,
                             long n_pixels, int dtype, void* stream) {
     GP_REQUIRE(x && wt && bias && ln_w && ln_b && y, "gp_dwconv_ln: null pointer");
@@ -293,15 +289,15 @@ extern "C" int gp_dwconv_ln(const void* x, const float* wt, const float* bias, c
     const int esz = dtype == GP_F16 ? 2 : 4;
     GP_REQUIRE(ct_ok(C, esz) && C / (16 / esz) >= 16, "gp_dwconv_ln: unsupported C=%d", C);
     GP_REQUIRE(KS == 3 || KS == 7, "gp_dwconv_ln: KS=%d unsupported (3 or 7)", KS);
-    GP_REQUIRE(W % 4 == 0, "gp_dwconv_ln: W=%d must be a multiple of 4", W);
+    GP_REQUIRE(W % 8 == 0, "gp_dwconv_ln: W=%d must be a multiple of 8", W);
     const long total = (long)B * H * W;
     GP_REQUIRE(n_pixels > 0 && n_pixels <= total, "gp_dwconv_ln: n_pixels out of range");
     const int CT = C / (16 / esz), PG = 256 / CT;
-    const long strips = (n_pixels + 3) / 4;
+    const long strips = (n_pixels + 7) / 8;
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
     dim3 grid(cdiv(strips, PG));
-#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels)
+#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels)
     if (dtype == GP_F16) { if (KS == 7) GP_DW(half_t, 7); else GP_DW(half_t, 3); }
     else { if (KS == 7) GP_DW(float, 7); else GP_DW(float, 3); }
 #undef GP_DW
@@ -326,9 +322,9 @@ extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void*
 
 extern "C" int gp_groupnorm_chunks(int HW) { return cdiv(HW, GN_PXB); }
 
-extern "C" int gp_groupnorm_stats(const void* x, float* partial, float* stats, int B, int HW, int C, int G,
-                                  float eps, int dtype, void* stream) {
-    GP_REQUIRE(x && partial && stats && B > 0 && HW > 0, "gp_groupnorm_stats: bad argument");
+extern "C" int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int G, int dtype,
+                                  void* stream) {
+    GP_REQUIRE(x && partial && B > 0 && HW > 0, "gp_groupnorm_stats: bad argument");
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_stats: bad dtype");
     const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
     GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_stats: unsupported C=%d G=%d", C, G);
@@ -342,24 +338,25 @@ extern "C" int gp_groupnorm_stats(const void* x, float* partial, float* stats, i
         hipLaunchKernelGGL(gn_partial_kernel<half_t>, dim3(chunks, B), dim3(256), 0, s, (const half_t*)x, partial, HW, C, G);
     else
         hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, B), dim3(256), 0, s, (const float*)x, partial, HW, C, G);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv((long)B * G, 256)), dim3(256), 0, s, partial, stats, B * G, G, chunks,
-                       1.0f / ((float)HW * cpg), eps);
     GP_LAUNCH_CHECK("gp_groupnorm_stats");
 }
 
-extern "C" int gp_groupnorm_apply(const void* x, const float* stats, const float* w, const float* b, void* y,
-                                  int B, int HW, int C, int G, int act, int ldy, int dtype, void* stream) {
-    GP_REQUIRE(x && stats && w && b && y && B > 0 && HW > 0, "gp_groupnorm_apply: bad argument");
+extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y,
+                                  int B, int HW, int C, int G, float eps, int act, int ldy, int dtype,
+                                  void* stream) {
+    GP_REQUIRE(x && partial && w && b && y && B > 0 && HW > 0, "gp_groupnorm_apply: bad argument");
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply: bad dtype");
     const int esz = dtype == GP_F16 ? 2 : 4;
-    GP_REQUIRE(ct_ok(C, esz) && G > 0 && C % G == 0, "gp_groupnorm_apply: unsupported C=%d G=%d", C, G);
+    GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_apply: unsupported C=%d G=%d", C, G);
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
-    dim3 grid(cdiv(HW, GN_PXB), B);
+    const int chunks = cdiv(HW, GN_PXB);
+    const float inv_count = 1.0f / ((float)HW * (C / G));
+    dim3 grid(chunks, B);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, stats, w, b, (half_t*)y, HW, C, G, act, ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, stats, w, b, (float*)y, HW, C, G, act, ldy);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps);
     GP_LAUNCH_CHECK("gp_groupnorm_apply");
 }

@@ -169,7 +169,7 @@ def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, p
 def convnext_stem(img, w, b, ln_w, ln_b, out, eps=1e-6):
     B, _, H, W_ = img.shape
     _contig(_chk(img, "img", torch.float32), "img")
-    check(_L().gp_convnext_stem(_ptr(img), _ptr(w), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, w.shape[0],
+    check(_L().gp_convnext_stem(_ptr(img), _ptr(w), _ptr(b), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, w.shape[1],
                                 eps, dtype_code(out.dtype), _stream()), "gp_convnext_stem")
     return out
 
@@ -194,13 +194,12 @@ def groupnorm_chunks(HW):
     return _L().gp_groupnorm_chunks(HW)
 
 
-def groupnorm(x, w, b, out, G, act, partial, stats, eps=1e-5, ldy=None):
+def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None):
     """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed."""
     B, HW, C = x.shape
     code = dtype_code(x.dtype)
-    check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), _ptr(stats), B, HW, C, G, eps, code, _stream()),
-          "gp_groupnorm_stats")
-    check(_L().gp_groupnorm_apply(_ptr(x), _ptr(stats), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, act,
+    check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), B, HW, C, G, code, _stream()), "gp_groupnorm_stats")
+    check(_L().gp_groupnorm_apply(_ptr(x), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, eps, act,
                                   C if ldy is None else ldy, code, _stream()), "gp_groupnorm_apply")
     return out
 
@@ -231,21 +230,21 @@ def pointwise_k3(xyz4, w, b, out):
 
 
 def pnp_conv1(xyz4, coord2d, w, out, B, R):
-    check(_L().gp_pnp_conv1(_ptr(xyz4), _ptr(_contig(coord2d, "coord2d")), _ptr(w), _ptr(out), B, R, w.shape[0],
+    check(_L().gp_pnp_conv1(_ptr(xyz4), _ptr(_contig(coord2d, "coord2d")), _ptr(w), _ptr(out), B, R, w.shape[1],
                             dtype_code(out.dtype), _stream()), "gp_pnp_conv1")
     return out
 
 
 def xyz_conv3x3_s2(xyz4, w, out, B, R):
-    check(_L().gp_xyz_conv3x3_s2(_ptr(xyz4), _ptr(w), _ptr(out), B, R, w.shape[0], dtype_code(out.dtype), _stream()),
+    check(_L().gp_xyz_conv3x3_s2(_ptr(xyz4), _ptr(w), _ptr(out), B, R, w.shape[1], dtype_code(out.dtype), _stream()),
           "gp_xyz_conv3x3_s2")
     return out
 
 
-def size_head(feat, w1, b1, w2, b2, mean_size, out):
+def size_head(feat, w1, b1, w2, b2, mean_size, out, scratch):
     B, HW, C = feat.shape
-    check(_L().gp_size_head(_ptr(_contig(feat, "feat")), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mean_size), _ptr(out), B,
-                            HW, C, w1.shape[0], dtype_code(feat.dtype), _stream()), "gp_size_head")
+    check(_L().gp_size_head(_ptr(_contig(feat, "feat")), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mean_size), _ptr(out),
+                            _ptr(scratch), B, HW, C, w1.shape[0], dtype_code(feat.dtype), _stream()), "gp_size_head")
     return out
 
 

@@ -96,7 +96,7 @@ class PoseNet(nn.Module):
         W = {}
         cfg = self.cfg
         g = lambda k: sd["backbone." + k]
-        W["stem.w"], W["stem.b"] = f32(g("stem_0.weight")), f32(g("stem_0.bias"))
+        W["stem.w"], W["stem.b"] = f32(g("stem_0.weight").reshape(-1, 48).t()), f32(g("stem_0.bias"))
         W["stem.ln_w"], W["stem.ln_b"] = f32(g("stem_1.weight")), f32(g("stem_1.bias"))
         for s, (d, n) in enumerate(zip(cfg.convnext_dims, cfg.convnext_depths)):
             if s > 0:
@@ -106,7 +106,7 @@ class PoseNet(nn.Module):
                 W[f"ds{s}.b"] = f32(g(p + "1.bias"))
             for b in range(n):
                 p, q = f"stages_{s}.blocks.{b}.", f"s{s}b{b}."
-                W[q + "dw_w"] = f32(g(p + "conv_dw.weight").reshape(d, 49).t())
+                W[q + "dw_w"] = lowp(g(p + "conv_dw.weight").reshape(d, 49).t())
                 W[q + "dw_b"] = f32(g(p + "conv_dw.bias"))
                 W[q + "ln_w"], W[q + "ln_b"] = f32(g(p + "norm.weight")), f32(g(p + "norm.bias"))
                 W[q + "fc1_w"], W[q + "fc1_b"] = lowp(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
@@ -132,7 +132,7 @@ class PoseNet(nn.Module):
                 W[q + "conv_w"] = f32(cw) if li == 0 else lowp(cw)
                 W[q + "conv_b"] = f32(sd[p + "conv.bias"])
                 d = p + "dcnv3."
-                W[q + "dw_w"] = f32(sd[d + "dw_conv.0.weight"].reshape(256, 9).t())
+                W[q + "dw_w"] = lowp(sd[d + "dw_conv.0.weight"].reshape(256, 9).t())
                 W[q + "dw_b"] = f32(sd[d + "dw_conv.0.bias"])
                 W[q + "ln_w"], W[q + "ln_b"] = f32(sd[d + "dw_conv.1.1.weight"]), f32(sd[d + "dw_conv.1.1.bias"])
                 W[q + "om_w"] = lowp(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
@@ -141,10 +141,10 @@ class PoseNet(nn.Module):
                 W[q + "out_w"], W[q + "out_b"] = lowp(sd[d + "output_proj.weight"]), f32(sd[d + "output_proj.bias"])
             else:
                 cw = sd[p + "weight"]
-                W[q + "conv_w"] = f32(cw) if li == 0 else lowp(cw.permute(0, 2, 3, 1).reshape(256, -1))
+                W[q + "conv_w"] = f32(cw.reshape(256, -1).t()) if li == 0 else lowp(cw.permute(0, 2, 3, 1).reshape(256, -1))
             W[q + "gn_w"], W[q + "gn_b"] = f32(sd[f"nocs_encoder.features.{i + 1}.weight"]), f32(sd[f"nocs_encoder.features.{i + 1}.bias"])
         W["red.w"], W["red.b"] = lowp(sd["feat_reducer.weight"].reshape(256, -1)), f32(sd["feat_reducer.bias"])
-        W["pnp.c0_w"] = f32(sd["pnp_net.features.0.weight"])
+        W["pnp.c0_w"] = f32(sd["pnp_net.features.0.weight"].reshape(128, -1).t())
         for li, i in enumerate((0, 3, 6)):
             if li > 0:
                 W[f"pnp.c{li}_w"] = lowp(sd[f"pnp_net.features.{i}.weight"].permute(0, 2, 3, 1).reshape(128, -1))
@@ -190,7 +190,7 @@ class PoseNet(nn.Module):
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
         chunks = ops.groupnorm_chunks(R * R)
-        buf["gn_partial"], buf["gn_stats"] = f(B * chunks * 32 * 2), f(B * 32 * 2)
+        buf["gn_partial"], buf["size_scratch"] = f(B * chunks * 32 * 2), f(B * cfg.feat_ts)
         buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["mask_out"], buf["size"] = f(B, 1, R, R), f(B, 3)
@@ -213,7 +213,7 @@ class PoseNet(nn.Module):
         B = x.shape[0]
         C = x.shape[-1]
         xv = x.view(B, -1, C)
-        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], buf["gn_stats"], ldy=ldy)
+        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy)
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
         """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows."""
@@ -251,7 +251,7 @@ class PoseNet(nn.Module):
         feat = x                                    # (B,8,8,1024)
         fc = dims[-1]
         feat2d = feat.view(B * 64, fc)
-        ops.size_head(feat.view(B, 64, fc), W["size.w1"], W["size.b1"], W["size.w2"], W["size.b2"], buf["mean_size"], buf["size"])
+        ops.size_head(feat.view(B, 64, fc), W["size.w1"], W["size.b1"], W["size.w2"], W["size.b2"], buf["mean_size"], buf["size"], buf["size_scratch"])
         self._xyz_head(W, "xyz_nocs_head", feat2d, B, buf, buf["nocs_nchw"], buf["nocs_nhwc4"])
         # ---- MAPEncoder (network/conv_pnp_net.py:303-332)
         cat2d = buf["feat_cat"].view(B * 64, 512)

@@ -95,15 +95,16 @@ int gp_gemm(const gp_gemm_desc* d, void* stream);
 
 /* ConvNeXt stem: conv4x4 s4 (3->C0, bias) + LayerNorm over channels (eps).  img is the
  * reference's NCHW fp32 `roi_img` (network/PoseNet.py:174); out is (B,H/4,W/4,C0) channels-last.
- * w is (C0,3,4,4) fp32 as stored in the checkpoint. C0 must be 128. */
+ * w is (48, C0) fp32 tap-major, k = c*16 + kh*4 + kw (the checkpoint's (C0,3,4,4) transposed by the host).
+ * C0 must be 128. */
 int gp_convnext_stem(const float* img, const float* w, const float* b, const float* ln_w, const float* ln_b,
                      void* out, int B, int H, int W, int C0, float eps, int dtype, void* stream);
 
 /* depth-wise KSxKS conv (pad KS/2, stride 1, bias) + LayerNorm over C (+ optional GELU):
  * ConvNeXt block front half (dw7x7 -> LN) and DCNv3's dw_conv branch (dw3x3 -> LN -> GELU,
- * ops_dcnv3/modules/dcnv3.py:277-296).  wt: (KS*KS, C) fp32 tap-major.  Only the first
+ * ops_dcnv3/modules/dcnv3.py:277-296).  wt: (KS*KS, C) tap-major, of `dtype`.  Only the first
  * `n_pixels` flat pixels (b,h,w order) are produced (DCNv3 consumes a prefix). */
-int gp_dwconv_ln(const void* x, const float* wt, const float* bias, const float* ln_w, const float* ln_b,
+int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b,
                  void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
                  void* stream);
 
@@ -112,14 +113,14 @@ int gp_layernorm(const void* x, const float* w, const float* b, void* y, long ro
                  int dtype, void* stream);
 
 /* GroupNorm (nn.GroupNorm(G, C), eps) over channels-last x (B, HW, C):
- *   gp_groupnorm_stats -> stats (B, G, 2) fp32 = (mean, rstd); partial is scratch of
- *   B*chunks*G*2 floats where chunks = gp_groupnorm_chunks(HW).
- *   gp_groupnorm_apply: y = act((x-mean)*rstd*w + b); y row stride ldy (concat targets). */
+ *   gp_groupnorm_stats -> partial (B, chunks, G, 2) fp32 = per-chunk (sum, sum of squares), chunks =
+ *   gp_groupnorm_chunks(HW), summed in a fixed order (bitwise reproducible);
+ *   gp_groupnorm_apply: finalises (mean, rstd) from `partial`, y = act((x-mean)*rstd*w + b); y row stride ldy
+ *   (concat targets); in-place (y == x, ldy == C) allowed. */
 int gp_groupnorm_chunks(int HW);
-int gp_groupnorm_stats(const void* x, float* partial, float* stats, int B, int HW, int C, int G, float eps,
-                       int dtype, void* stream);
-int gp_groupnorm_apply(const void* x, const float* stats, const float* w, const float* b, void* y, int B,
-                       int HW, int C, int G, int act, int ldy, int dtype, void* stream);
+int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int G, int dtype, void* stream);
+int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y, int B,
+                       int HW, int C, int G, float eps, int act, int ldy, int dtype, void* stream);
 
 /* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), channels-last (xyz_head.py:264). */
 int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
@@ -139,21 +140,22 @@ int gp_pointwise_k3(const float* xyz4, const float* w, const float* b, void* y, 
                     int dtype, void* stream);
 
 /* ConvPnPNet first conv: Conv2d(5,Cout,3,s2,p1,bias=False) on cat(ivfc (B*HW,4) fp32, roi_coord_2d
- * (B,2,R,R) fp32 NCHW) (network/PoseNet.py:196-197, conv_pnp_net.py:72-83). w (Cout,5,3,3) fp32.
+ * (B,2,R,R) fp32 NCHW) (network/PoseNet.py:196-197, conv_pnp_net.py:72-83). w (45, Cout) fp32 tap-major, k = ci*9+kh*3+kw.
  * out (B,R/2,R/2,Cout) dtype. */
 int gp_pnp_conv1(const float* xyz4, const float* coord2d, const float* w, void* y, int B, int R, int Cout,
                  int dtype, void* stream);
 
 /* Plain Conv2d(3,Cout,3,s2,p1,bias=False) on the (B*HW,4) fp32 coordinate map: first MAPEncoder layer
- * when use_dcn='' (conv_pnp_net.py:258-272). w (Cout,3,3,3) fp32. */
+ * when use_dcn='' (conv_pnp_net.py:258-272). w (27, Cout) fp32 tap-major. */
 int gp_xyz_conv3x3_s2(const float* xyz4, const float* w, void* y, int B, int R, int Cout, int dtype,
                       void* stream);
 
 /* SizeHead (network/pose_head.py:30-42) + mean-size residual (network/PoseNet.py:199-202):
  * feat (B,HW,C); w1 (F,C) / b1 (F) with eval BatchNorm folded in; w2 (3,F), b2 (3);
- * out size (B,3) fp32 = head + mean_size/||mean_size||. */
+ * out size (B,3) fp32 = head + mean_size/||mean_size||; scratch: B*F floats. */
 int gp_size_head(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
-                 const float* mean_size, float* size, int B, int HW, int C, int F, int dtype, void* stream);
+                 const float* mean_size, float* size, float* scratch, int B, int HW, int C, int F, int dtype,
+                 void* stream);
 
 /* Pose tail: fc_r/fc_t/fc_z (conv_pnp_net.py:190-199), rot6d -> R (pose_utils/rot_reps.py:34-55),
  * centroid/z back-projection and allocentric -> egocentric (pose_from_pred_centroid_z.py:60-157,
