@@ -23,7 +23,7 @@ class GemmDesc(Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("ldx", c_int), ("ldc", c_int), ("ldres", c_int),
                 ("epilogue", c_int), ("out_f32", c_int), ("splitk", c_int),
                 ("B", c_int), ("H", c_int), ("Win", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int),
-                ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int)]
+                ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int), ("variant", c_int)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)

@@ -73,6 +73,50 @@ __device__ __forceinline__ void epi_store(const GemmKP& p, int m, int n, f32x4 v
     }
 }
 
+// ---- epilogue pieces with every global LOAD hoisted ahead of the first global STORE of a tile.
+// gfx950's vmcnt counts loads and stores together, in issue order: a load whose data is waited for after a
+// store also waits for that store's acknowledgement (~1 us under load).  The first version loaded bias /
+// gamma / residual per 4-element group between the stores and spent ~15 us per 256x256 tile doing so
+// (scripts/gemm_bench.py abl.*, K = 64).
+template <typename T> struct Res4 { typedef half4 type; };
+template <> struct Res4<float> { typedef f32x4 type; };
+
+template <typename T>
+__device__ __forceinline__ typename Res4<T>::type load_res4(const GemmKP& p, int m, int n) {
+    return *reinterpret_cast<const typename Res4<T>::type*>(reinterpret_cast<const T*>(p.res) + (long)m * p.ldres + n);
+}
+
+template <typename T>
+__device__ __forceinline__ f32x4 epi_apply(int epi, f32x4 v, const f32x4& b, const f32x4& g, const typename Res4<T>::type& r) {
+    v += b;
+    switch (epi) {
+        case GP_EPI_GELU:
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            break;
+        case GP_EPI_RELU:
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            break;
+        case GP_EPI_LRELU:
+            for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.1f * v[j];
+            break;
+        case GP_EPI_SCALE_RES:
+            for (int j = 0; j < 4; ++j) v[j] = (float)r[j] + g[j] * v[j];
+            break;
+        default: break;
+    }
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ void store4(const GemmKP& p, int m, int n, const f32x4& v) {
+    if (p.out_f32 || sizeof(T) == 4) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+    } else {
+        half4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.C) + (long)m * p.ldc + n) = o;
+    }
+}
+
 template <typename T> __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b);
 template <> __device__ __forceinline__ void mma<half_t>(f32x4& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a),
@@ -210,7 +254,37 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmKP p) {
         buf ^= 1;
     }
 
-    // ---- epilogue straight from registers: lane holds C[m][n..n+3]
+    // ---- epilogue straight from registers: lane holds C[m][n..n+3]; all loads before the first store
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+                if (n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = acc[nt][mt];
+            }
+        }
+        return;
+    }
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 b4[4], g4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+        b4[nt] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+        g4[nt] = (p.epi == GP_EPI_SCALE_RES && n < p.N) ? *reinterpret_cast<const f32x4*>(p.gamma + n) : zero4;
+    }
+    typename Res4<T>::type r4[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int m = m0 + wm * 64 + mt * 16 + fr, n = n0 + wn * 64 + nt * 16 + fq * 4;
+            for (int j = 0; j < 4; ++j) r4[mt][nt][j] = 0;
+            if (p.epi == GP_EPI_SCALE_RES && m < p.M && n < p.N) r4[mt][nt] = load_res4<T>(p, m, n);
+        }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wm * 64 + mt * 16 + fr;
@@ -218,11 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmKP p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            if (n >= p.N) continue;
-            if (p.splitk > 1)
-                *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = acc[nt][mt];
-            else
-                epi_store<T>(p, m, n, acc[nt][mt]);
+            if (n < p.N) store4<T>(p, m, n, epi_apply<T>(p.epi, acc[nt][mt], b4[nt], g4[nt], r4[mt][nt]));
         }
     }
 }
@@ -236,6 +306,230 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmKP p) {
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < p.splitk; ++s) v += *reinterpret_cast<const f32x4*>(p.ws + ((long)s * p.M + m) * p.N + n);
     epi_store<T>(p, m, n, v);
+}
+
+
+// =====================================================================================================
+// Large-tile variant: BM = WM*MT*16 pixels x BN = WN*NT*16 channels, 8 waves, K step 128 bytes.
+//   A: 256 x 256 (waves 2m x 4n, wave tile 128m x 64n)      B: 256 x 128 (waves 4m x 2n, wave tile 64 x 64)
+// Per FLOP it moves half (A) / three quarters (B) of the 128x128 kernel's L2->LDS bytes and, with the
+// 128x64 wave tile, 25 % fewer LDS fragment bytes -- the 128x128 kernel is LDS-pipe bound (ds_write of the
+// register-staged tiles + fragment reads exceed the MFMA time, profiles/r01a).  Global->LDS goes through
+// LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write; the LDS image stays lane-linear and the
+// bank-conflict swizzle is applied to the per-lane SOURCE address (chunk ^= row & 7), the same involution as
+// on the fragment reads.  Padding / out-of-range rows read a zero page.  Two LDS stages: the DMA of step
+// t+1 is issued before the MFMAs of step t and drained (vmcnt(0)) right before the barrier that ends step t.
+// Epilogue: each wave transposes its accumulators through a private 8 KB LDS slab (32 rows x 64 fp32,
+// XOR-swizzled) so that global stores/residual loads are whole 128-B row segments.
+__device__ __attribute__((aligned(256))) unsigned int gp_zero_page[64];
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr, +1 KB).
+// Issued from inline asm so that hipcc does not count it: with the builtin form hipcc puts an
+// s_waitcnt vmcnt(0) in front of the first ds_read after it (it cannot tell the DMA's LDS destination from the
+// buffer being read), which serialises the DMA of step t+1 with the MFMAs of step t.  The kernel waits for
+// these loads itself (s_waitcnt vmcnt(0) before the barrier that publishes the stage).  M0 carries the LDS
+// destination and is restored (hipcc reserves it).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int NS>
+__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP p) {
+    static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int EPT = 16 / sizeof(T), KPT = 128 / sizeof(T);
+    constexpr int XI = BM / 8 / NW, WI = BN / 8 / NW;  // LDS-DMA instructions per wave per K step
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(NS * STAGE >= NW * 8192, "epilogue slabs must fit");
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
+    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+    const T* zero = reinterpret_cast<const T*>(gp_zero_page);
+
+    // ---- DMA source state: instruction i of this wave fills rows (i*NW + wave)*8 .. +8 of a tile;
+    //      lane -> row +(lane>>3), LDS chunk lane&7 holds logical chunk (lane&7) ^ (row&7)
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
+    long xbase[XI];
+    int hi0[XI], wi0[XI];
+    bool xok[XI];
+    const T* wsrc[WI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int m = m0 + (i * NW + wave) * 8 + lrow;
+        xok[i] = m < p.M;
+        if (p.conv) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, r = m - b * hw;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            hi0[i] = ho * p.stride - p.pad;
+            wi0[i] = wo * p.stride - p.pad;
+            xbase[i] = (long)b * p.H * p.Win;
+        } else {
+            hi0[i] = wi0[i] = 0;
+            xbase[i] = (long)m * p.ldx + lchunk * EPT;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int n = n0 + (i * NW + wave) * 8 + lrow;
+        wsrc[i] = n < p.N ? W + (long)n * p.K + lchunk * EPT : nullptr;
+    }
+    const int cpt = p.conv ? p.Cin / KPT : 1;
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    auto stage = [&](int buf, int kt) {
+        const unsigned xs = lds0 + buf * STAGE + wave * 1024;
+        const unsigned ws = xs + BM * 128;
+        int kh = 0, kw = 0, ci = 0;
+        if (p.conv) {
+            const int tap = kt / cpt;
+            ci = (kt - tap * cpt) * KPT + lchunk * EPT;
+            kh = tap / p.KW;
+            kw = tap - kh * p.KW;
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const T* src = zero;
+            if (p.conv) {
+                const int hi = hi0[i] + kh, wi = wi0[i] + kw;
+                if (xok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.Win)
+                    src = X + (xbase[i] + (long)hi * p.Win + wi) * p.Cin + ci;
+            } else if (xok[i]) {
+                src = X + xbase[i] + (long)kt * KPT;
+            }
+            glds16(src, xs + i * NW * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const T* src = wsrc[i] ? wsrc[i] + (long)kt * KPT : zero;
+            glds16(src, ws + i * NW * 1024);
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
+    const int xfo = (wm * MT * 16 + fr) * 128, wfo = (wn * NT * 16 + fr) * 128;
+    auto compute = [&](int buf) {
+        const char* xs = smem + buf * STAGE;
+        const char* ws = xs + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = ((ks * 4 + fq) ^ sw) << 4;
+            uint4 xf[MT], wf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + wfo + t * 2048 + co);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + xfo + t * 2048 + co);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
+        }
+    };
+
+    // NS-stage ring: steps t+1 .. t+NS-1 are in flight while step t is multiplied.  Each wave waits for its own
+    // DMAs of step t+1 with a COUNTED vmcnt (the NS-2 younger steps stay in flight across the barrier).
+    constexpr int G = XI + WI;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < p.nkt) stage(i, i);
+    if (p.nkt > NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0, nbuf = NS - 1;
+    for (int kt = 0; kt < p.nkt; ++kt) {
+        const bool more = kt + NS - 1 < p.nkt;
+        if (more) stage(nbuf, kt + NS - 1);
+        compute(buf);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
+
+    // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
+    //      Lane owns output columns n .. n+3 (fixed) of rows i*4 + (lane>>4); every global load (bias, gamma,
+    //      the whole residual tile in f16 mode) is issued before the first store.
+    char* slab = smem + wave * 8192;
+    const int en = n0 + wn * NT * 16 + (lane & 15) * 4, er = lane >> 4;
+    const int mb = m0 + wm * MT * 16;
+    const bool nok = en < p.N;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
+    const bool sres = p.epi == GP_EPI_SCALE_RES;
+    const f32x4 g4 = (sres && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
+    constexpr bool PRE = sizeof(T) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
+    typename Res4<T>::type r4[PRE ? MT / 2 : 1][8];
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < MT / 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + j * 32 + i * 4 + er;
+                for (int e = 0; e < 4; ++e) r4[PRE ? j : 0][i][e] = 0;
+                if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<T>(p, m, en);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < MT / 2; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = h * 16 + fr;
+                *reinterpret_cast<f32x4*>(slab + row * 256 + (((nt * 4 + fq) ^ (row & 7)) << 4)) = acc[nt][2 * j + h];
+            }
+#pragma unroll
+        for (int i0 = 0; i0 < 8; i0 += 4) {
+            if (!PRE) {   // fp32 storage: residual in batches of 4 rows (register budget)
+#pragma unroll
+                for (int i = i0; i < i0 + 4; ++i) {
+                    const int m = mb + j * 32 + i * 4 + er;
+                    for (int e = 0; e < 4; ++e) r4[0][i][e] = 0;
+                    if (sres && nok && m < p.M) r4[0][i] = load_res4<T>(p, m, en);
+                }
+            }
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) {
+                const int row = i * 4 + er, chunk = lane & 15;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
+                const int m = mb + j * 32 + row;
+                if (m < p.M && nok) store4<T>(p, m, en, epi_apply<T>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]));
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int NS> void launch_big(GemmKP& p, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles_n = cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -284,6 +578,33 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     const double bytes = xbytes + (double)d->N * d->K * esz + (double)d->M * d->N * (d->out_f32 ? 4 : esz) +
                          (d->epilogue == GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
+    // variant: 1 = 128x128 register-staged (+split-K), 2 = 256x128 LDS-DMA, 3 = 256x256 LDS-DMA, 0 = pick
+    int variant = d->variant;
+    if (variant == 0) {
+        // measured per shape (scripts/gemm_bench.py, profiles/r01b): 256x256 wins when it fills the chip and N is a
+        // multiple of 256; otherwise 128x128 LDS-DMA at two workgroups per CU; split-K stays on the register-staged kernel
+        const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
+        if (p.splitk > 1) variant = 1;
+        else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 3;  // (fp32 256x256 spills)
+        else variant = 4;
+    }
+    GP_REQUIRE(variant >= 1 && variant <= 5 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    if (variant == 5) {
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 4>(p, s); else launch_big<float, 2, 2, 4, 4, 4>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 4) {
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 3) {
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 2) {
+        if (d->dtype == GP_F16) launch_big<half_t, 4, 2, 4, 4, 3>(p, s); else launch_big<float, 4, 2, 4, 4, 3>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     dim3 grid(p.tiles_m * p.tiles_n, p.splitk);
     if (d->dtype == GP_F16)
         hipLaunchKernelGGL(gemm_kernel<half_t>, grid, dim3(256), 0, s, p);

@@ -74,7 +74,7 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None):
+         ldres=None, conv=None, splitk=None, variant=0):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
     dt = x.dtype
@@ -102,7 +102,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz)
+        splitk = auto_splitk(M, N, K, esz) if variant in (0, 1) else 1
     d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None
@@ -111,12 +111,12 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
         d.workspace = _workspace(x.device, splitk * M * N).data_ptr()
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
-    d.epilogue, d.out_f32, d.splitk, d.dtype = epilogue, out_f32, splitk, code
+    d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
     check(_L().gp_gemm(ctypes.byref(d), _stream()), "gp_gemm")
     return out
 
 
-def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE):
+def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -124,7 +124,7 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
     if out is None:
         out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
-         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad))
+         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant)
     return out
 
 

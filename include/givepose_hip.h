@@ -90,6 +90,7 @@ typedef struct gp_gemm_desc {
     /* conv mode */
     int B, H, Win, Cin, KH, KW, stride, pad, Ho, Wo;
     int dtype;
+    int variant; /* 0 = choose by shape; 1 = 128x128 tile (split-K capable), 2 = 256x128, 3 = 256x256 LDS-DMA tiles */
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 

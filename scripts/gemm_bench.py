@@ -6,6 +6,7 @@ import torch
 from givepose_amd import ops
 
 B = int(os.environ.get("B", 64))
+VAR = int(os.environ.get("VAR", 0))
 dt = torch.float16
 dev = "cuda"
 shapes = []
@@ -23,6 +24,10 @@ shapes.append(("enc.om@64", dict(M=B * 1024, N=108, K=256, f32out=True)))
 shapes.append(("pnp.conv@32", dict(conv=dict(B=B, H=32, W=32, Cin=128, KH=3, KW=3, stride=2, pad=1), N=128)))
 shapes.append(("fc1", dict(M=B, N=2048, K=8192, epi=ops.EPI_LRELU)))
 shapes.append(("red", dict(M=B * 64, N=256, K=1024)))
+for k in (64, 512, 2048):
+    for nm, e in (("none", ops.EPI_NONE), ("gelu", ops.EPI_GELU), ("relu", ops.EPI_RELU)):
+        shapes.append((f"abl.k{k}.{nm}", dict(M=16384, N=2048, K=k, epi=e)))
+shapes.append(("abl.k512.f32out", dict(M=16384, N=2048, K=512, f32out=True)))
 shapes.append(("square4k", dict(M=4096, N=4096, K=4096)))
 shapes.append(("square8k", dict(M=8192, N=8192, K=8192)))
 
@@ -44,7 +49,7 @@ def run(name, s):
     kw = {}
     if epi == ops.EPI_SCALE_RES:
         kw = dict(gamma=torch.randn(N, device=dev), residual=out)
-    f = lambda: ops.gemm(x, w, out, bias=bias, epilogue=epi, conv=conv, **kw)
+    f = lambda: ops.gemm(x, w, out, bias=bias, epilogue=epi, conv=conv, variant=VAR, **kw)
     for _ in range(3):
         f()
     torch.cuda.synchronize()

@@ -99,6 +99,35 @@ def test_conv_implicit_gemm(dt, cfg):
     assert rel_err(out, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+def test_gemm_large_tile_variants(dt, variant):
+    """256x128 / 256x256 LDS-DMA tiles: ragged M and N edges, every epilogue, ld strides, conv with padding."""
+    o = ops()
+    for (M, N, K) in [(256, 256, 128), (700, 388, 256), (1000, 512, 64 if dt == torch.float16 else 32), (130, 12, 512)]:
+        x, w, b = q(rnd(M, K, seed=61), dt), q(rnd(N, K, seed=62, scale=K ** -0.5), dt), rnd(N, seed=63)
+        res, gamma = q(rnd(M, N, seed=64), dt), rnd(N, seed=65)
+        lin = x @ w.t() + b
+        for epi, ref in ((o.EPI_NONE, lin), (o.EPI_GELU, F.gelu(lin)), (o.EPI_SCALE_RES, res + gamma * lin)):
+            out = torch.zeros(M, N + 4, dtype=dt, device="cuda")
+            kw = dict(gamma=gamma.cuda(), residual=res.to("cuda", dt)) if epi == o.EPI_SCALE_RES else {}
+            o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda(), epilogue=epi, variant=variant, ldc=N + 4, **kw)
+            assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, K, epi)
+            assert float(out[:, N:].abs().max()) == 0.0
+        out32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out32, bias=b.cuda(), variant=variant)
+        assert rel_err(out32, lin) < (2e-5 if dt == torch.float32 else 2e-4)
+    for cfg in (dict(B=3, H=16, Cin=128, Cout=256, k=3, s=1, p=1), dict(B=5, H=16, Cin=64, Cout=128, k=3, s=2, p=1),
+                dict(B=4, H=8, Cin=128, Cout=256, k=2, s=2, p=0)):
+        B, H, Cin, Cout, k, s_, p_ = (cfg[n] for n in ("B", "H", "Cin", "Cout", "k", "s", "p"))
+        x = q(rnd(B, Cin, H, H, seed=66), dt)
+        w = q(rnd(Cout, Cin, k, k, seed=67, scale=(Cin * k * k) ** -0.5), dt)
+        ref = F.conv2d(x, w, None, stride=s_, padding=p_).permute(0, 2, 3, 1)
+        out = o.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to("cuda", dt),
+                            w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", dt), k, k, s_, p_, variant=variant)
+        assert rel_err(out, ref) < TOL[dt], cfg
+
+
 def test_gemm_rejects_bad_shapes():
     o = ops()
     from givepose_amd._lib import GivePoseHipError
