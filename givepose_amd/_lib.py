@@ -37,7 +37,7 @@ PROTOTYPES = {
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
     "gp_dwconv_ln": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, c_long, c_int, _P], c_int),
     "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, _P], c_int),
-    "gp_groupnorm_chunks": ([c_int], c_int),
+    "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),
     "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_upsample_bilinear2x": ([_P, _P] + [c_int] * 5 + [_P], c_int),

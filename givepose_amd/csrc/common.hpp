@@ -79,6 +79,36 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
+// GELU for fp16 storage: erf(z) ~ clamp(z * P(z^2)), z clamped to +-3.1, P of degree 8 (weighted least squares
+// fit, scripts: DESIGN.md section 5); max |GELU error| 3.8e-5 in fp32 Horner = 1/13 of an fp16 ulp at |x| ~ 1.
+// No transcendental, and written on 2-vectors so that hipcc emits v_pk_{mul,fma,max,min}_f32: a wave64 VALU
+// instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the fc1 epilogues and the
+// GroupNorm+GELU passes VALU bound.  The fp32 storage path keeps gelu_erf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const f32x2 lim = {3.1f, 3.1f}, one = {1.f, 1.f};
+    f32x2 z = x * 0.70710678118654752440f;
+    z = __builtin_elementwise_min(__builtin_elementwise_max(z, -lim), lim);
+    const f32x2 t = z * z;
+    f32x2 p = {2.617556483e-08f, 2.617556483e-08f};
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.372215252e-06f, -1.372215252e-06f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.173028381e-05f, 3.173028381e-05f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-4.296133993e-04f, -4.296133993e-04f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.825224470e-03f, 3.825224470e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-2.390606701e-02f, -2.390606701e-02f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.091638282e-01f, 1.091638282e-01f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-3.738503158e-01f, -3.738503158e-01f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.127893329e+00f, 1.127893329e+00f});
+    f32x2 e = __builtin_elementwise_min(__builtin_elementwise_max(z * p, -one), one);
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
+}
+__device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }
+
+template <typename T> __device__ __forceinline__ float gelu_for(float v) {
+    if constexpr (sizeof(T) == 2) return gelu_poly1(v); else return gelu_erf(v);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case GP_ACT_GELU: return gelu_erf(v);
@@ -97,5 +127,8 @@ __device__ __forceinline__ float group_max(float v, int width) {
     for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// 256 zero bytes per translation unit: source of LDS-DMA lanes that fall in padding / out of range
+static __device__ __attribute__((aligned(256), used)) unsigned int gp_zero_page_tu[64];
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -91,7 +91,12 @@ __device__ __forceinline__ f32x4 epi_apply(int epi, f32x4 v, const f32x4& b, con
     v += b;
     switch (epi) {
         case GP_EPI_GELU:
-            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            if constexpr (sizeof(T) == 2) {
+                const f32x2 lo = gelu_poly2(f32x2{v[0], v[1]}), hi = gelu_poly2(f32x2{v[2], v[3]});
+                v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            } else {
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
             break;
         case GP_EPI_RELU:
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
@@ -321,7 +326,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmKP p) {
 // t+1 is issued before the MFMAs of step t and drained (vmcnt(0)) right before the barrier that ends step t.
 // Epilogue: each wave transposes its accumulators through a private 8 KB LDS slab (32 rows x 64 fp32,
 // XOR-swizzled) so that global stores/residual loads are whole 128-B row segments.
-__device__ __attribute__((aligned(256))) unsigned int gp_zero_page[64];
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
 
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
-    const T* zero = reinterpret_cast<const T*>(gp_zero_page);
+    const T* zero = reinterpret_cast<const T*>(gp_zero_page_tu);
 
     // ---- DMA source state: instruction i of this wave fills rows (i*NW + wave)*8 .. +8 of a tile;
     //      lane -> row +(lane>>3), LDS chunk lane&7 holds logical chunk (lane&7) ^ (row&7)

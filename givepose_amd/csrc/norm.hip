@@ -43,6 +43,24 @@ template <> __device__ __forceinline__ void load_f32<float>(const float* p, floa
     for (int i = 0; i < 4; ++i) o[i] = a[i];
 }
 
+// acc[e] += in[e] * w[e] over one 16-byte vector.  f16: v_fma_mix_f32 takes the two fp16 operands straight from
+// the packed registers (fp32 accumulate), 1 VALU op per MAC instead of cvt + cvt + fma: the depth-wise kernels are
+// VALU bound once their traffic is on-chip.
+template <typename T> __device__ __forceinline__ void mac16(float* acc, const Vec16<T>& a, const Vec16<T>& w);
+template <> __device__ __forceinline__ void mac16<float>(float* acc, const Vec16<float>& a, const Vec16<float>& w) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaf(a.e[e], w.e[e], acc[e]);
+}
+template <> __device__ __forceinline__ void mac16<half_t>(float* acc, const Vec16<half_t>& a, const Vec16<half_t>& w) {
+    const unsigned* au = reinterpret_cast<const unsigned*>(&a.u);
+    const unsigned* wu = reinterpret_cast<const unsigned*>(&w.u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * j]) : "v"(au[j]), "v"(wu[j]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * j + 1]) : "v"(au[j]), "v"(wu[j]));
+    }
+}
+
 // ---------------------------------------------------------------------------- dwconv + LN (+act)
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const T* __restrict__ wt,
@@ -85,9 +103,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
             for (int kw = 0; kw < KS; ++kw) {
                 const Vec16<T> wv = load16<T>(wt + (long)(kh * KS + kw) * C + cs * VEC);
 #pragma unroll
-                for (int p = 0; p < PPT; ++p)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[p][e] += in[p + kw].get(e) * wv.get(e);
+                for (int p = 0; p < PPT; ++p) mac16<T>(acc[p], in[p + kw], wv);
             }
         }
     }
@@ -123,9 +139,159 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
         const float rstd = rsqrtf(v[p] * invC + eps);
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.set(e, apply_act(acc[p][e] * rstd * gw[e] + gb[e], act));
+        for (int e = 0; e < VEC; ++e) {
+            const float val = acc[p][e] * rstd * gw[e] + gb[e];
+            o.set(e, act == GP_ACT_GELU ? gelu_for<T>(val) : apply_act(val, act));
+        }
         store16<T>(y + (pix0 + p) * C + cs * VEC, o);
     }
+}
+
+// ---------------------------------------------------------------------------- dw7x7 + LN, LDS-tiled
+// The strip kernel above re-reads every input row 7x and every filter tap once per 8 pixels from L1/L2 and is
+// bound by L2->L1 traffic (12x read amplification, profiles/r01a).  Here a workgroup owns a TW x TH output tile
+// of one image and walks the channels in slabs of 16 lanes x 16 B: the (TW+6) x (TH+6) halo tile of a slab and
+// its 49 taps are brought in by LDS-DMA (zero page for the padding) into one of two LDS buffers while the
+// previous slab is being convolved out of the other; accumulators of all slabs stay in registers until the
+// LayerNorm statistics over C are known.  Halo amplification: 3.1x (8x8 tile), all of it L2 hits.
+
+__device__ __forceinline__ void glds16_n(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <typename T, int NSLAB>
+__global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restrict__ x, const T* __restrict__ wt,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ lnw,
+                                                               const float* __restrict__ lnb, T* __restrict__ y, int H,
+                                                               int W, int C, float eps, int dbg) {
+    constexpr int VEC = Vec16<T>::N, SC = 16 * VEC, KS = 7, R = 3;
+    constexpr int PPT = 2, SPR = 4;                  // 32 pixel-threads x 2 px: strips per tile row
+    constexpr int TW = SPR * PPT, TH = 32 / SPR;     // 8 x 8 output tile, 8 waves (2 per SIMD)
+    constexpr int IW = TW + 6, IH = TH + 6, NPX = IW * IH;
+    constexpr int IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
+    constexpr int BUF = (IN_INSTR + W_INSTR) * 1024;
+    constexpr int NBUF = NSLAB > 1 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tpr = W / TW, tpi = tpr * (H / TH);
+    const int b = blockIdx.x / tpi, tin = blockIdx.x - b * tpi;
+    const int h0 = (tin / tpr) * TH, w0 = (tin % tpr) * TW;
+    const T* xb = x + (long)b * H * W * C;
+    const T* zero = reinterpret_cast<const T*>(gp_zero_page_tu);
+
+    auto issue = [&](int s, int buf) {
+        const unsigned base = lds0 + buf * BUF;
+        for (int ins = wave; ins < IN_INSTR; ins += 8) {
+            const int i = ins * 64 + lane, px = i >> 4, sl = i & 15;
+            const int iy = px / IW, ix = px - iy * IW;
+            const int gy = h0 - R + iy, gx = w0 - R + ix;
+            const T* src = zero;
+            if (px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                src = xb + ((long)gy * W + gx) * C + s * SC + sl * VEC;
+            glds16_n(src, base + ins * 1024);
+        }
+        for (int ins = wave; ins < W_INSTR; ins += 8) {
+            const int i = ins * 64 + lane, tap = i >> 4, sl = i & 15;
+            const T* src = tap < 49 ? wt + (long)tap * C + s * SC + sl * VEC : zero;
+            glds16_n(src, base + (IN_INSTR + ins) * 1024);
+        }
+    };
+
+    const int slot = tid & 15, pt = tid >> 4;
+    const int row = pt / SPR, col0 = (pt % SPR) * PPT;
+    float acc[NSLAB][PPT][VEC];
+    if (dbg != 2) issue(0, 0);
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < NSLAB && dbg != 2) issue(s + 1, (s + 1) & 1);
+        const char* in_s = dsm + (s & (NBUF - 1)) * BUF;
+        const char* w_s = in_s + IN_INSTR * 1024;
+        {
+            float bv[VEC];
+            load_f32<T>(bias + s * SC + slot * VEC, bv);
+#pragma unroll
+            for (int p = 0; p < PPT; ++p)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[s][p][e] = bv[e];
+        }
+#pragma unroll 1
+        for (int kh = 0; kh < (dbg == 1 ? 0 : KS); ++kh) {
+            Vec16<T> in[KS + PPT - 1];
+#pragma unroll
+            for (int c = 0; c < KS + PPT - 1; ++c)
+                in[c].u = *reinterpret_cast<const uint4*>(in_s + (((row + kh) * IW + col0 + c) * 16 + slot) * 16);
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                Vec16<T> wv;
+                wv.u = *reinterpret_cast<const uint4*>(w_s + ((kh * KS + kw) * 16 + slot) * 16);
+#pragma unroll
+                for (int p = 0; p < PPT; ++p) mac16<T>(acc[s][p], in[p + kw], wv);
+            }
+        }
+        if (NBUF == 1) __syncthreads();
+    }
+    // LayerNorm over C: channels of a pixel live in NSLAB registers-slabs x 16 lanes
+    float sum[PPT], var[PPT];
+    const float invC = 1.0f / C;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a += acc[s][p][e];
+        sum[p] = group_sum(a, 16) * invC;
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                acc[s][p][e] -= sum[p];
+                a += acc[s][p][e] * acc[s][p][e];
+            }
+        var[p] = rsqrtf(group_sum(a, 16) * invC + eps);
+    }
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        float gw[VEC], gb[VEC];
+        load_f32<T>(lnw + s * SC + slot * VEC, gw);
+        load_f32<T>(lnb + s * SC + slot * VEC, gb);
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.set(e, acc[s][p][e] * var[p] * gw[e] + gb[e]);
+            store16<T>(y + (((long)b * H + h0 + row) * W + w0 + col0 + p) * C + s * SC + slot * VEC, o);
+        }
+    }
+}
+
+template <typename T, int NSLAB>
+void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B,
+                      int H, int W, int C, float eps, hipStream_t s, int dbg = 0) {
+    constexpr int NPX = 14 * 14, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
+    constexpr int LDS = (NSLAB > 1 ? 2 : 1) * (IN_INSTR + W_INSTR) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tiled_kernel<T, NSLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dwconv7_ln_tiled_kernel<T, NSLAB>), dim3(B * (H / 8) * (W / 8)), dim3(512), LDS, s, (const T*)x,
+                       (const T*)wt, bias, lnw, lnb, (T*)y, H, W, C, eps, dbg);
 }
 
 // ---------------------------------------------------------------------------- row LayerNorm
@@ -172,12 +338,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------- GroupNorm
-constexpr int GN_PXB = 256;  // pixels per statistics block
+// pixels per block: 256 when that still gives >= 1024 blocks, else 64 (small maps are latency bound)
+static inline int gn_pxb(int B, int HW) { return ((long)B * HW / 256 >= 1024 || HW < 64) ? 256 : 64; }
 
 // partial[((b*chunks + chunk)*G + g)*2 + {0,1}] = (sum, sum of squares) of this chunk, fixed order
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
-                                                         int HW, int C, int G) {
+                                                         int HW, int C, int G, int GN_PXB) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float part[256][4][2];
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
@@ -228,7 +395,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
                                                        const float* __restrict__ w, const float* __restrict__ bb,
                                                        T* __restrict__ y, int HW, int C, int G, int act, int ldy,
-                                                       int chunks, float inv_count, float eps) {
+                                                       int chunks, float inv_count, float eps, int GN_PXB) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float st[256][2];
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
@@ -266,8 +433,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int p = p0 + pl; p < p1; p += PG) {
         const Vec16<T> v = load16<T>(xb + (long)p * C);
         Vec16<T> o;
+        if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v.get(e) * sc[e] + sh[e], act));
+            for (int e = 0; e < VEC; e += 2) {
+                const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
+                o.set(e, g[0]);
+                o.set(e + 1, g[1]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v.get(e) * sc[e] + sh[e], act));
+        }
         store16<T>(yb + (long)p * ldy, o);
     }
 }
@@ -296,6 +472,26 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     const long strips = (n_pixels + 7) / 8;
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
+    const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
+    if (act >= 100) act = GP_ACT_NONE;
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && H % 8 == 0 && W % 8 == 0) {
+        const int nslab = C / (16 * (16 / esz));
+        bool done = true;
+        if (dtype == GP_F16) {
+            if (nslab == 1) launch_dw7_tiled<half_t, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 2) launch_dw7_tiled<half_t, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 4) launch_dw7_tiled<half_t, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 8) launch_dw7_tiled<half_t, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else done = false;
+        } else {
+            if (nslab == 2) launch_dw7_tiled<float, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 4) launch_dw7_tiled<float, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 8) launch_dw7_tiled<float, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else if (nslab == 16) launch_dw7_tiled<float, 16>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            else done = false;
+        }
+        if (done) GP_LAUNCH_CHECK("gp_dwconv_ln");
+    }
     dim3 grid(cdiv(strips, PG));
 #define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels)
     if (dtype == GP_F16) { if (KS == 7) GP_DW(half_t, 7); else GP_DW(half_t, 3); }
@@ -320,7 +516,7 @@ extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void*
     GP_LAUNCH_CHECK("gp_layernorm");
 }
 
-extern "C" int gp_groupnorm_chunks(int HW) { return cdiv(HW, GN_PXB); }
+extern "C" int gp_groupnorm_chunks(int B, int HW) { return cdiv(HW, gn_pxb(B, HW)); }
 
 extern "C" int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int G, int dtype,
                                   void* stream) {
@@ -331,13 +527,13 @@ extern "C" int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, 
     const int cpg = C / G;
     GP_REQUIRE((cpg >= vec && cpg % vec == 0) || (cpg < vec && vec % cpg == 0 && vec / cpg <= 4),
                "gp_groupnorm_stats: channels per group %d unsupported", cpg);
-    const int chunks = cdiv(HW, GN_PXB);
+    const int pxb = gn_pxb(B, HW), chunks = cdiv(HW, pxb);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 3.0 * B * HW * C, (double)B * HW * C * esz);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(gn_partial_kernel<half_t>, dim3(chunks, B), dim3(256), 0, s, (const half_t*)x, partial, HW, C, G);
+        hipLaunchKernelGGL(gn_partial_kernel<half_t>, dim3(chunks, B), dim3(256), 0, s, (const half_t*)x, partial, HW, C, G, pxb);
     else
-        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, B), dim3(256), 0, s, (const float*)x, partial, HW, C, G);
+        hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(chunks, B), dim3(256), 0, s, (const float*)x, partial, HW, C, G, pxb);
     GP_LAUNCH_CHECK("gp_groupnorm_stats");
 }
 
@@ -351,12 +547,12 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
-    const int chunks = cdiv(HW, GN_PXB);
+    const int pxb = gn_pxb(B, HW), chunks = cdiv(HW, pxb);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(chunks, B);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
     GP_LAUNCH_CHECK("gp_groupnorm_apply");
 }

@@ -190,8 +190,8 @@ def layernorm(x, w, b, out, eps=1e-6):
     return out
 
 
-def groupnorm_chunks(HW):
-    return _L().gp_groupnorm_chunks(HW)
+def groupnorm_chunks(B, HW):
+    return _L().gp_groupnorm_chunks(B, HW)
 
 
 def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None):

@@ -189,7 +189,7 @@ class PoseNet(nn.Module):
         buf["cols"] = f(B * 64, 9 * 256)
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
-        chunks = ops.groupnorm_chunks(R * R)
+        chunks = max(ops.groupnorm_chunks(B, r * r) for r in (8, 16, 32, 64))
         buf["gn_partial"], buf["size_scratch"] = f(B * chunks * 32 * 2), f(B * cfg.feat_ts)
         buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)

@@ -115,10 +115,10 @@ int gp_layernorm(const void* x, const float* w, const float* b, void* y, long ro
 
 /* GroupNorm (nn.GroupNorm(G, C), eps) over channels-last x (B, HW, C):
  *   gp_groupnorm_stats -> partial (B, chunks, G, 2) fp32 = per-chunk (sum, sum of squares), chunks =
- *   gp_groupnorm_chunks(HW), summed in a fixed order (bitwise reproducible);
+ *   gp_groupnorm_chunks(B, HW), summed in a fixed order (bitwise reproducible);
  *   gp_groupnorm_apply: finalises (mean, rstd) from `partial`, y = act((x-mean)*rstd*w + b); y row stride ldy
  *   (concat targets); in-place (y == x, ldy == C) allowed. */
-int gp_groupnorm_chunks(int HW);
+int gp_groupnorm_chunks(int B, int HW);
 int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int G, int dtype, void* stream);
 int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y, int B,
                        int HW, int C, int G, float eps, int act, int ldy, int dtype, void* stream);

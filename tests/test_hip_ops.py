@@ -253,7 +253,7 @@ def test_groupnorm(dt, C, HW, act):
     ref = F.group_norm(x, 32, gw, gb, 1e-5)
     ref = (F.gelu(ref) if act == "gelu" else F.relu(ref)).permute(0, 2, 1)
     xd = x.permute(0, 2, 1).contiguous().to("cuda", dt)
-    partial = torch.empty(B * o.groupnorm_chunks(HW) * 64, device="cuda")
+    partial = torch.empty(B * o.groupnorm_chunks(B, HW) * 64, device="cuda")
     wide = torch.zeros(B, HW, 2 * C, dtype=dt, device="cuda")
     o.groupnorm(xd, gw.cuda(), gb.cuda(), wide[:, :, C:], 32, o.ACT_GELU if act == "gelu" else o.ACT_RELU, partial, ldy=2 * C)
     assert rel_err(wide[:, :, C:], ref) < TOL[dt]
