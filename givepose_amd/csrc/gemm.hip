@@ -32,6 +32,7 @@ struct GemmKP {
     int M, N, K, ldx, ldc, ldres, epi, out_f32;
     int conv, H, Win, Cin, KW, stride, pad, Ho, Wo;
     int tiles_m, tiles_n, nkt, kt_per_split, splitk;
+    int dbg;  // timing-only ablations of the large-tile kernel: 1 = no in-loop DMA, 2 = no MFMA/LDS reads (wrong results)
 };
 
 template <typename T>
@@ -343,7 +344,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS>
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP p) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
     constexpr int NW = WM * WN;
@@ -370,32 +371,40 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     const T* zero = reinterpret_cast<const T*>(gp_zero_page_tu);
 
     // ---- DMA source state: instruction i of this wave fills rows (i*NW + wave)*8 .. +8 of a tile;
-    //      lane -> row +(lane>>3), LDS chunk lane&7 holds logical chunk (lane&7) ^ (row&7)
+    //      lane -> row +(lane>>3), LDS chunk lane&7 holds logical chunk (lane&7) ^ (row&7).
+    //      Per lane: one base pointer per row (tap (0,0) / k = 0) and a bit mask of the in-bounds filter taps, so a
+    //      K step costs a scalar offset + add + select per DMA (the first version recomputed (hi, wi) and a 64-bit
+    //      address per DMA: 1.8 VALU ops per MFMA, which competes with the MFMAs for the SIMD's issue slots).
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
-    long xbase[XI];
-    int hi0[XI], wi0[XI];
-    bool xok[XI];
-    const T* wsrc[WI];
+    const char* xptr[XI];
+    unsigned xmask[XI];
+    const char* wptr[WI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int m = m0 + (i * NW + wave) * 8 + lrow;
-        xok[i] = m < p.M;
+        const bool ok = m < p.M;
         if (p.conv) {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, r = m - b * hw;
             const int ho = r / p.Wo, wo = r - ho * p.Wo;
-            hi0[i] = ho * p.stride - p.pad;
-            wi0[i] = wo * p.stride - p.pad;
-            xbase[i] = (long)b * p.H * p.Win;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            xptr[i] = reinterpret_cast<const char*>(X + (((long)b * p.H + hi0) * p.Win + wi0) * p.Cin + lchunk * EPT);
+            unsigned mk = 0;
+            const int KH = p.K / (p.KW * p.Cin);
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if (ok && (unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.Win)
+                        mk |= 1u << (kh * p.KW + kw);
+            xmask[i] = mk;
         } else {
-            hi0[i] = wi0[i] = 0;
-            xbase[i] = (long)m * p.ldx + lchunk * EPT;
+            xptr[i] = reinterpret_cast<const char*>(X + (long)m * p.ldx + lchunk * EPT);
+            xmask[i] = ok ? 1u : 0u;
         }
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int n = n0 + (i * NW + wave) * 8 + lrow;
-        wsrc[i] = n < p.N ? W + (long)n * p.K + lchunk * EPT : nullptr;
+        wptr[i] = n < p.N ? reinterpret_cast<const char*>(W + (long)n * p.K + lchunk * EPT) : nullptr;
     }
     const int cpt = p.conv ? p.Cin / KPT : 1;
 
@@ -403,30 +412,21 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     auto stage = [&](int buf, int kt) {
         const unsigned xs = lds0 + buf * STAGE + wave * 1024;
         const unsigned ws = xs + BM * 128;
-        int kh = 0, kw = 0, ci = 0;
+        long xoff;      // wave-uniform byte offset of this K step from the row base pointer
+        unsigned bit = 1u;
         if (p.conv) {
             const int tap = kt / cpt;
-            ci = (kt - tap * cpt) * KPT + lchunk * EPT;
-            kh = tap / p.KW;
-            kw = tap - kh * p.KW;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            xoff = (((long)kh * p.Win + kw) * p.Cin + (kt - tap * cpt) * KPT) * (long)sizeof(T);
+            bit = 1u << tap;
+        } else {
+            xoff = (long)kt * 128;
         }
+        const char* zp = reinterpret_cast<const char*>(zero);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const T* src = zero;
-            if (p.conv) {
-                const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-                if (xok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.Win)
-                    src = X + (xbase[i] + (long)hi * p.Win + wi) * p.Cin + ci;
-            } else if (xok[i]) {
-                src = X + xbase[i] + (long)kt * KPT;
-            }
-            glds16(src, xs + i * NW * 1024);
-        }
+        for (int i = 0; i < XI; ++i) glds16((xmask[i] & bit) ? xptr[i] + xoff : zp, xs + i * NW * 1024);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const T* src = wsrc[i] ? wsrc[i] + (long)kt * KPT : zero;
-            glds16(src, ws + i * NW * 1024);
-        }
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * 128 : zp, ws + i * NW * 1024);
     };
 
     f32x4 acc[NT][MT];
@@ -437,27 +437,96 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
 
     const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
     const int xfo = (wm * MT * 16 + fr) * 128, wfo = (wn * NT * 16 + fr) * 128;
+    // DB: fragments of K sub-step 1 are fetched from LDS while the MFMAs of sub-step 0 run (explicit second
+    // register set) and the MFMA cluster is bracketed by s_setprio -- an A/B arm, see scripts/gemm_bench.py.
     auto compute = [&](int buf) {
-        const char* xs = smem + buf * STAGE;
-        const char* ws = xs + BM * 128;
+        const char* xs = smem + buf * STAGE + xfo;
+        const char* ws = smem + buf * STAGE + BM * 128 + wfo;
+        if constexpr (DB) {
+            const int co0 = ((0 * 4 + fq) ^ sw) << 4, co1 = ((1 * 4 + fq) ^ sw) << 4;
+            uint4 xf0[MT], wf0[NT], xf1[MT], wf1[NT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 4 + fq) ^ sw) << 4;
-            uint4 xf[MT], wf[NT];
+            for (int t = 0; t < NT; ++t) wf0[t] = *reinterpret_cast<const uint4*>(ws + t * 2048 + co0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + wfo + t * 2048 + co);
+            for (int t = 0; t < MT; ++t) xf0[t] = *reinterpret_cast<const uint4*>(xs + t * 2048 + co0);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + xfo + t * 2048 + co);
+            for (int t = 0; t < NT; ++t) wf1[t] = *reinterpret_cast<const uint4*>(ws + t * 2048 + co1);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xf1[t] = *reinterpret_cast<const uint4*>(xs + t * 2048 + co1);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf0[nt], xf0[mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf1[nt], xf1[mt]);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((ks * 4 + fq) ^ sw) << 4;
+                uint4 xf[MT], wf[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 2048 + co);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 2048 + co);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
+            }
+        }
+    };
+
+    constexpr int G = XI + WI;
+    if constexpr (DB && NS == 2) {
+        // Software-pipelined schedule (2 LDS stages, 2 fragment register sets F0/F1), per K step t:
+        //   read F1 <- (t, k-half 1) | MFMA(F0) | wait own LDS reads + own DMA(t+1), barrier |
+        //   DMA(t+2) into the buffer just freed | read F0 <- (t+1, k-half 0) | MFMA(F1)
+        // so every LDS fragment read and the DMA issue run under the MFMAs of the other half step instead of
+        // all eight waves hitting the LDS together right after the barrier.
+        uint4 xf0[MT], wf0[NT], xf1[MT], wf1[NT];
+        const int co0 = ((0 * 4 + fq) ^ sw) << 4, co1 = ((1 * 4 + fq) ^ sw) << 4;
+        auto rd = [&](int buf, int co, uint4* xf, uint4* wf) {
+            const char* xs = smem + buf * STAGE + xfo;
+            const char* ws = smem + buf * STAGE + BM * 128 + wfo;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 2048 + co);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 2048 + co);
+        };
+        auto mm = [&](const uint4* xf, const uint4* wf) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        rd(0, co0, xf0, wf0);
+        if (p.nkt > 1) stage(1, 1);
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            const int buf = kt & 1;
+            rd(buf, co1, xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < p.nkt) stage(buf, kt + 2);
+            if (kt + 1 < p.nkt) rd(buf ^ 1, co0, xf0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(xf1, wf1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-
+        __syncthreads();
+    } else {
     // NS-stage ring: steps t+1 .. t+NS-1 are in flight while step t is multiplied.  Each wave waits for its own
     // DMAs of step t+1 with a COUNTED vmcnt (the NS-2 younger steps stay in flight across the barrier).
-    constexpr int G = XI + WI;
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i)
         if (i < p.nkt) stage(i, i);
@@ -467,13 +536,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     int buf = 0, nbuf = NS - 1;
     for (int kt = 0; kt < p.nkt; ++kt) {
         const bool more = kt + NS - 1 < p.nkt;
-        if (more) stage(nbuf, kt + NS - 1);
-        compute(buf);
+        if (more && p.dbg != 1) stage(nbuf, kt + NS - 1);
+        if (p.dbg != 2) compute(buf);
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf = buf + 1 == NS ? 0 : buf + 1;
         nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
     }
 
     // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
@@ -529,11 +599,11 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     }
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS> void launch_big(GemmKP& p, hipStream_t s) {
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -560,6 +630,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(d->KW > 0 && d->stride > 0 && d->pad >= 0, "gp_gemm: bad conv geometry");
         GP_REQUIRE(d->Cin % KPT == 0, "gp_gemm: conv Cin=%d must be a multiple of %d", d->Cin, KPT);
         GP_REQUIRE(d->K == d->KH * d->KW * d->Cin, "gp_gemm: conv K=%d != KH*KW*Cin", d->K);
+        GP_REQUIRE(d->KH * d->KW <= 32, "gp_gemm: at most 32 filter taps");
         const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, Wo = (d->Win + 2 * d->pad - d->KW) / d->stride + 1;
         GP_REQUIRE(Ho == d->Ho && Wo == d->Wo, "gp_gemm: conv output %dx%d != expected %dx%d", d->Ho, d->Wo, Ho, Wo);
         GP_REQUIRE((long)d->B * Ho * Wo == d->M, "gp_gemm: conv M=%d != B*Ho*Wo", d->M);
@@ -583,16 +654,25 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          (d->epilogue == GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
     // variant: 1 = 128x128 register-staged (+split-K), 2 = 256x128 LDS-DMA, 3 = 256x256 LDS-DMA, 0 = pick
-    int variant = d->variant;
+    int variant = d->variant % 10;
+    p.dbg = d->variant / 10;
     if (variant == 0) {
         // measured per shape (scripts/gemm_bench.py, profiles/r01b): 256x256 wins when it fills the chip and N is a
         // multiple of 256; otherwise 128x128 LDS-DMA at two workgroups per CU; split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
-        else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 3;  // (fp32 256x256 spills)
-        else variant = 4;
+        else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 6;  // (fp32 256x256 spills)
+        else variant = d->dtype == GP_F16 ? 7 : 4;   // 6 / 7 = software-pipelined schedule (+3..16 % in one-process A/B)
     }
-    GP_REQUIRE(variant >= 1 && variant <= 5 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    GP_REQUIRE(variant >= 1 && variant <= 7 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    if (variant == 6) {   // A/B arms: explicit fragment double buffering (f16 only; fp32 falls back to 3 / 4)
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 7) {
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     if (variant == 5) {
         if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 4>(p, s); else launch_big<float, 2, 2, 4, 4, 4>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");

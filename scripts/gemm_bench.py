@@ -6,7 +6,8 @@ import torch
 from givepose_amd import ops
 
 B = int(os.environ.get("B", 64))
-VAR = int(os.environ.get("VAR", 0))
+VARS = [int(v) for v in os.environ.get("VARS", "0").split(",")]
+ROUNDS = int(os.environ.get("ROUNDS", 3))
 dt = torch.float16
 dev = "cuda"
 shapes = []
@@ -49,21 +50,23 @@ def run(name, s):
     kw = {}
     if epi == ops.EPI_SCALE_RES:
         kw = dict(gamma=torch.randn(N, device=dev), residual=out)
-    f = lambda: ops.gemm(x, w, out, bias=bias, epilogue=epi, conv=conv, variant=VAR, **kw)
-    for _ in range(3):
-        f()
-    torch.cuda.synchronize()
-    n = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / n * 1e3
     fl = 2.0 * M * N * K
-    by = (x.numel() + w.numel()) * 2 + out.numel() * out.element_size()
-    print(f"{name:18s} M={M:7d} N={N:5d} K={K:5d}  {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s  {by / us / 1e3:8.1f} GB/s  tiles={((M+127)//128)*((N+127)//128)}")
+    res = {}
+    for rnd in range(ROUNDS):                      # interleaved rounds in one process (A/B arms share the device state)
+        for var in VARS:
+            f = lambda: ops.gemm(x, w, out, bias=bias, epilogue=epi, conv=conv, variant=var, **kw)
+            for _ in range(2):
+                f()
+            n = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            res.setdefault(var, []).append(e0.elapsed_time(e1) / n * 1e3)
+    txt = "  ".join(f"v{var}: {sorted(t)[len(t)//2]:7.1f}us {fl / sorted(t)[len(t)//2] / 1e6:6.0f}TF" for var, t in res.items())
+    print(f"{name:18s} M={M:7d} N={N:5d} K={K:5d}  {txt}")
 
 only = sys.argv[1:] 
 for name, s in shapes:
