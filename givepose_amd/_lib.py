@@ -23,7 +23,8 @@ class GemmDesc(Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("ldx", c_int), ("ldc", c_int), ("ldres", c_int),
                 ("epilogue", c_int), ("out_f32", c_int), ("splitk", c_int),
                 ("B", c_int), ("H", c_int), ("Win", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int),
-                ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int), ("variant", c_int)]
+                ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
+                ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)
@@ -39,7 +40,7 @@ PROTOTYPES = {
     "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, _P], c_int),
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),
-    "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 3 + [_P], c_int),
+    "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 4 + [_P], c_int),
     "gp_upsample_bilinear2x": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_deconv_col2im": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_xyz_out_layer": ([_P] * 5 + [c_int] * 4 + [_P], c_int),

@@ -32,6 +32,8 @@ struct GemmKP {
     int M, N, K, ldx, ldc, ldres, epi, out_f32;
     int conv, H, Win, Cin, KW, stride, pad, Ho, Wo;
     int tiles_m, tiles_n, nkt, kt_per_split, splitk;
+    float* gn_partial;  // fused GroupNorm statistics (large-tile kernels): (B, HW/64, G, 2) chunk sums, or null
+    int gn_cpg, gn_hw;
     int dbg;  // timing-only ablations of the large-tile kernel: 1 = no in-loop DMA, 2 = no MFMA/LDS reads (wrong results)
 };
 
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
                 if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<T>(p, m, en);
             }
     }
+    float gsum = 0.f, gsq = 0.f;
 #pragma unroll
     for (int j = 0; j < MT / 2; ++j) {
 #pragma unroll
@@ -593,8 +596,29 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
                 const int row = i * 4 + er, chunk = lane & 15;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
                 const int m = mb + j * 32 + row;
-                if (m < p.M && nok) store4<T>(p, m, en, epi_apply<T>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]));
+                if (m < p.M && nok) {
+                    const f32x4 o = epi_apply<T>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
+                    store4<T>(p, m, en, o);
+                    gsum += (o[0] + o[1]) + (o[2] + o[3]);
+                    gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                }
             }
+        }
+        // fused GroupNorm statistics: one (sum, sum of squares) per 64 output rows and channel group, fixed order
+        if (p.gn_partial && (j & 1)) {
+            float a = gsum, q = gsq;
+            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+            if (p.gn_cpg == 8) { a += __shfl_xor(a, 1, 64); q += __shfl_xor(q, 1, 64); }
+            const int mrow = mb + (j - 1) * 32;
+            if (er == 0 && nok && mrow < p.M && (p.gn_cpg == 4 || (lane & 1) == 0)) {
+                const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
+                const int b = mrow / p.gn_hw, ch = (mrow - b * p.gn_hw) >> 6;
+                float* o = p.gn_partial + (((long)b * cpi + ch) * G + en / p.gn_cpg) * 2;
+                o[0] = a;
+                o[1] = q;
+            }
+            gsum = gsq = 0.f;
         }
     }
 }
@@ -626,6 +650,13 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     p.X = d->X; p.W = d->W; p.bias = d->bias; p.gamma = d->gamma; p.res = d->residual; p.C = d->C; p.ws = d->workspace;
     p.M = d->M; p.N = d->N; p.K = d->K; p.ldx = d->ldx; p.ldc = d->ldc; p.ldres = d->ldres;
     p.epi = d->epilogue; p.out_f32 = d->out_f32;
+    if (d->gn_partial) {
+        GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
+                   "gp_gemm: fused GroupNorm needs 4 or 8 channels per group");
+        GP_REQUIRE(d->gn_hw > 0 && d->gn_hw % 64 == 0 && d->M % d->gn_hw == 0, "gp_gemm: fused GroupNorm needs HW %% 64 == 0");
+        GP_REQUIRE(d->splitk <= 1, "gp_gemm: fused GroupNorm excludes split-K");
+        p.gn_partial = d->gn_partial; p.gn_cpg = d->N / d->gn_groups; p.gn_hw = d->gn_hw;
+    }
     if (d->KH > 0) {
         GP_REQUIRE(d->KW > 0 && d->stride > 0 && d->pad >= 0, "gp_gemm: bad conv geometry");
         GP_REQUIRE(d->Cin % KPT == 0, "gp_gemm: conv Cin=%d must be a multiple of %d", d->Cin, KPT);
@@ -661,10 +692,12 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         // multiple of 256; otherwise 128x128 LDS-DMA at two workgroups per CU; split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
+        else if (p.gn_partial) variant = (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) ? 6 : (d->dtype == GP_F16 ? 7 : 4);
         else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 6;  // (fp32 256x256 spills)
         else variant = d->dtype == GP_F16 ? 7 : 4;   // 6 / 7 = software-pipelined schedule (+3..16 % in one-process A/B)
     }
     GP_REQUIRE(variant >= 1 && variant <= 7 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    GP_REQUIRE(!(p.gn_partial && variant == 1), "gp_gemm: fused GroupNorm needs a large-tile variant");
     if (variant == 6) {   // A/B arms: explicit fragment double buffering (f16 only; fp32 falls back to 3 / 4)
         if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");

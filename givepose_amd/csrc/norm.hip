@@ -538,8 +538,8 @@ extern "C" int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, 
 }
 
 extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y,
-                                  int B, int HW, int C, int G, float eps, int act, int ldy, int dtype,
-                                  void* stream) {
+                                  int B, int HW, int C, int G, float eps, int act, int ldy, int chunks_in,
+                                  int dtype, void* stream) {
     GP_REQUIRE(x && partial && w && b && y && B > 0 && HW > 0, "gp_groupnorm_apply: bad argument");
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply: bad dtype");
     const int esz = dtype == GP_F16 ? 2 : 4;
@@ -547,9 +547,9 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
-    const int pxb = gn_pxb(B, HW), chunks = cdiv(HW, pxb);
+    const int pxb = gn_pxb(B, HW), chunks = chunks_in > 0 ? chunks_in : cdiv(HW, pxb);
     const float inv_count = 1.0f / ((float)HW * (C / G));
-    dim3 grid(chunks, B);
+    dim3 grid(cdiv(HW, pxb), B);
     if (dtype == GP_F16)
         hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
     else

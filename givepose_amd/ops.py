@@ -74,7 +74,7 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None, variant=0):
+         ldres=None, conv=None, splitk=None, variant=0, gn=None):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
     dt = x.dtype
@@ -102,7 +102,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz) if variant in (0, 1) else 1
+        splitk = auto_splitk(M, N, K, esz) if (variant in (0, 1) and gn is None) else 1
     d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None
@@ -112,11 +112,13 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
+    if gn is not None:       # (partial buffer, groups, pixels per image): fused GroupNorm statistics of the output
+        d.gn_partial, d.gn_groups, d.gn_hw = gn[0].data_ptr(), gn[1], gn[2]
     check(_L().gp_gemm(ctypes.byref(d), _stream()), "gp_gemm")
     return out
 
 
-def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0):
+def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -124,7 +126,7 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
     if out is None:
         out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
-         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant)
+         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn)
     return out
 
 
@@ -194,13 +196,15 @@ def groupnorm_chunks(B, HW):
     return _L().gp_groupnorm_chunks(B, HW)
 
 
-def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None):
-    """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed."""
+def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=False):
+    """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed.  fused_stats: ``partial``
+    was already filled by the producing gemm(..., gn=(partial, G, HW)) in 64-row chunks."""
     B, HW, C = x.shape
     code = dtype_code(x.dtype)
-    check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), B, HW, C, G, code, _stream()), "gp_groupnorm_stats")
+    if not fused_stats:
+        check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), B, HW, C, G, code, _stream()), "gp_groupnorm_stats")
     check(_L().gp_groupnorm_apply(_ptr(x), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, eps, act,
-                                  C if ldy is None else ldy, code, _stream()), "gp_groupnorm_apply")
+                                  C if ldy is None else ldy, HW // 64 if fused_stats else 0, code, _stream()), "gp_groupnorm_apply")
     return out
 
 

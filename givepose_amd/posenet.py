@@ -190,7 +190,7 @@ class PoseNet(nn.Module):
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
         chunks = max(ops.groupnorm_chunks(B, r * r) for r in (8, 16, 32, 64))
-        buf["gn_partial"], buf["size_scratch"] = f(B * chunks * 32 * 2), f(B * cfg.feat_ts)
+        buf["gn_partial"], buf["size_scratch"] = f(B * max(chunks, R * R // 64) * 32 * 2), f(B * cfg.feat_ts)
         buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["mask_out"], buf["size"] = f(B, 1, R, R), f(B, 3)
@@ -209,11 +209,16 @@ class PoseNet(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ launch sequence
-    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None):
+    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None, fused=False):
+        """GroupNorm(32)+act in place (or into a concat target); fused: the producing GEMM already wrote the statistics."""
         B = x.shape[0]
         C = x.shape[-1]
         xv = x.view(B, -1, C)
-        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy)
+        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy, fused_stats=fused)
+
+    @staticmethod
+    def _gnarg(buf, hw):
+        return (buf["gn_partial"], 32, hw)
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
         """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows."""
@@ -226,8 +231,8 @@ class PoseNet(nn.Module):
                 r *= 2
                 cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"])
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
-            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst)
-            self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf)
+            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r))
+            self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True)
             cur = dst
         ops.xyz_out_layer(cur.view(B, r * r, 256), W[head + ".out_w"], W[head + ".out_b"], out_nchw, out_nhwc4)
 
@@ -273,18 +278,21 @@ class PoseNet(nn.Module):
                 ops.dcnv3_forward_into(buf[f"e_proj{li}"], om, om[:, 72:], buf[f"e_g{li}"], 3, 2, 1, 1, 4, 64, 1.0,
                                        off_ld=108, mask_ld=108, mask_is_logits=True)
                 y = buf[f"e_o{li}"]
-                ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"])
+                ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"],
+                         gn=self._gnarg(buf, ro * ro))
+                fused = True
             else:
                 y = buf[f"e_o{li}"]
+                fused = li > 0
                 if li == 0:
                     ops.xyz_conv3x3_s2(buf["nocs_nhwc4"], W[q + "conv_w"], y, B, r)
                 else:
-                    ops.conv2d_nhwc(prev, W[q + "conv_w"], 3, 3, 2, 1, out=y)
+                    ops.conv2d_nhwc(prev, W[q + "conv_w"], 3, 3, 2, 1, out=y, gn=self._gnarg(buf, ro * ro))
             if li < 2:
-                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf)
+                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf, fused=fused)
                 prev = y
             else:   # last layer normalises straight into the right half of feat_cat (PoseNet.py:193)
-                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf, out=cat2d[:, 256:], ldy=512)
+                self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf, out=cat2d[:, 256:], ldy=512, fused=fused)
         ops.gemm(feat2d, W["red.w"], cat2d, bias=W["red.b"], ldc=512)
         self._xyz_head(W, "xyz_deform_head", cat2d, B, buf, buf["ivfc_nchw"], buf["ivfc_nhwc4"])
         # ---- ConvPnPNet (network/conv_pnp_net.py:137-201)
@@ -292,8 +300,9 @@ class PoseNet(nn.Module):
         p = ops.pnp_conv1(buf["ivfc_nhwc4"], buf["roi_coord_2d"], W["pnp.c0_w"], buf["p0"], B, R)
         self._gn(p, W["pnp.g0_w"], W["pnp.g0_b"], ACT_RELU, buf)
         for li in (1, 2):
-            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"])
-            self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf)
+            hw = nxt_hw = (32 >> li) ** 2
+            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"], gn=self._gnarg(buf, hw))
+            self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf, fused=True)
             p = nxt
         ops.gemm(p.view(B, 8192), W["pnp.fc1_w"], buf["fc1"], bias=W["pnp.fc1_b"], epilogue=EPI_LRELU)
         ops.gemm(buf["fc1"], W["pnp.fc2_w"], buf["hh"], bias=W["pnp.fc2_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048)

@@ -90,6 +90,11 @@ typedef struct gp_gemm_desc {
     /* conv mode */
     int B, H, Win, Cin, KH, KW, stride, pad, Ho, Wo;
     int dtype;
+    /* optional fused GroupNorm statistics of the OUTPUT (large-tile variants, no split-K): per 64 output rows and
+     * channel group (sum, sum of squares) -> gn_partial (M/64, gn_groups, 2) fp32, i.e. (B, HW/64, G, 2) when
+     * M = B*gn_hw; consumed by gp_groupnorm_apply(..., chunks = gn_hw/64). NULL = off. */
+    float* gn_partial;
+    int gn_groups, gn_hw;
     int variant; /* 0 = choose by shape; 1 = 128x128 tile (split-K capable), 2 = 256x128, 3 = 256x256 LDS-DMA tiles */
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
@@ -121,7 +126,8 @@ int gp_layernorm(const void* x, const float* w, const float* b, void* y, long ro
 int gp_groupnorm_chunks(int B, int HW);
 int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int G, int dtype, void* stream);
 int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y, int B,
-                       int HW, int C, int G, float eps, int act, int ldy, int dtype, void* stream);
+                       int HW, int C, int G, float eps, int act, int ldy, int chunks /* 0 = gp_groupnorm_chunks */,
+                       int dtype, void* stream);
 
 /* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), channels-last (xyz_head.py:264). */
 int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);

@@ -262,6 +262,26 @@ def test_groupnorm(dt, C, HW, act):
     assert rel_err(xd, ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [dict(B=3, H=16, Cin=128, Cout=256, s=1), dict(B=2, H=16, Cin=64, Cout=128, s=2), dict(B=1, H=32, Cin=64, Cout=256, s=1)])
+def test_conv_with_fused_groupnorm_stats(dt, cfg):
+    """GroupNorm statistics produced by the conv epilogue (64-row chunks) == statistics pass, end result vs torch."""
+    o = ops()
+    B, H, Cin, Cout, s_ = (cfg[n] for n in ("B", "H", "Cin", "Cout", "s"))
+    x = q(rnd(B, Cin, H, H, seed=70), dt)
+    w = q(rnd(Cout, Cin, 3, 3, seed=71, scale=(Cin * 9) ** -0.5), dt)
+    gw, gb = 1 + 0.1 * rnd(Cout, seed=72), 0.1 * rnd(Cout, seed=73)
+    conv = F.conv2d(x, w, None, stride=s_, padding=1)
+    ref = F.gelu(F.group_norm(q(conv, dt) if dt == torch.float16 else conv, 32, gw, gb, 1e-5)).permute(0, 2, 3, 1)
+    Ho = conv.shape[-1]
+    partial = torch.zeros(B * max(Ho * Ho // 64, 4) * 64, device="cuda")
+    out = o.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to("cuda", dt), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", dt),
+                        3, 3, s_, 1, gn=(partial, 32, Ho * Ho))
+    ov = out.view(B, Ho * Ho, Cout)
+    o.groupnorm(ov, gw.cuda(), gb.cuda(), ov, 32, o.ACT_GELU, partial, fused_stats=True)
+    assert rel_err(out, ref) < (TOL[dt] if dt == torch.float32 else 6e-3)
+
+
 # ----------------------------------------------------------------------------------------------- small ops
 @pytest.mark.parametrize("dt", DT)
 def test_stem(dt):
