@@ -346,14 +346,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false>
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128>
 __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP p) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    constexpr int EPT = 16 / sizeof(T), KPT = 128 / sizeof(T);
-    constexpr int XI = BM / 8 / NW, WI = BN / 8 / NW;  // LDS-DMA instructions per wave per K step
-    constexpr int STAGE = (BM + BN) * 128;
+    // RB = bytes of K per LDS row and per K step: 128 (two MFMA k-groups per step) or 64 (one; half the stage
+    // size, so twice the stages / DMA bytes in flight fit the 160 KB LDS)
+    static_assert(RB == 128 || (RB == 64 && !DB), "RB");
+    constexpr int EPT = 16 / sizeof(T), KPT = RB / sizeof(T), CPR = RB / 16, RPI = 1024 / RB;
+    constexpr int XI = BM / RPI / NW, WI = BN / RPI / NW;  // LDS-DMA instructions per wave per K step
+    constexpr int STAGE = (BM + BN) * RB;
     static_assert(NS * STAGE >= NW * 8192, "epilogue slabs must fit");
     __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
 
@@ -377,13 +380,14 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     //      Per lane: one base pointer per row (tap (0,0) / k = 0) and a bit mask of the in-bounds filter taps, so a
     //      K step costs a scalar offset + add + select per DMA (the first version recomputed (hi, wi) and a 64-bit
     //      address per DMA: 1.8 VALU ops per MFMA, which competes with the MFMAs for the SIMD's issue slots).
-    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lrow & 7);
+    const int lrow = lane / CPR;
+    const int lchunk = RB == 128 ? ((lane & 7) ^ (lrow & 7)) : ((lane & 3) ^ ((-(lrow >> 2)) & 3));
     const char* xptr[XI];
     unsigned xmask[XI];
     const char* wptr[WI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int m = m0 + (i * NW + wave) * 8 + lrow;
+        const int m = m0 + (i * NW + wave) * RPI + lrow;
         const bool ok = m < p.M;
         if (p.conv) {
             const int hw = p.Ho * p.Wo;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int n = n0 + (i * NW + wave) * 8 + lrow;
+        const int n = n0 + (i * NW + wave) * RPI + lrow;
         wptr[i] = n < p.N ? reinterpret_cast<const char*>(W + (long)n * p.K + lchunk * EPT) : nullptr;
     }
     const int cpt = p.conv ? p.Cin / KPT : 1;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
     auto stage = [&](int buf, int kt) {
         const unsigned xs = lds0 + buf * STAGE + wave * 1024;
-        const unsigned ws = xs + BM * 128;
+        const unsigned ws = xs + BM * RB;
         long xoff;      // wave-uniform byte offset of this K step from the row base pointer
         unsigned bit = 1u;
         if (p.conv) {
@@ -422,13 +426,13 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
             xoff = (((long)kh * p.Win + kw) * p.Cin + (kt - tap * cpt) * KPT) * (long)sizeof(T);
             bit = 1u << tap;
         } else {
-            xoff = (long)kt * 128;
+            xoff = (long)kt * RB;
         }
         const char* zp = reinterpret_cast<const char*>(zero);
 #pragma unroll
         for (int i = 0; i < XI; ++i) glds16((xmask[i] & bit) ? xptr[i] + xoff : zp, xs + i * NW * 1024);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * 128 : zp, ws + i * NW * 1024);
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * RB : zp, ws + i * NW * 1024);
     };
 
     f32x4 acc[NT][MT];
@@ -438,13 +442,24 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
-    const int xfo = (wm * MT * 16 + fr) * 128, wfo = (wn * NT * 16 + fr) * 128;
+    const int xfo = (wm * MT * 16 + fr) * RB, wfo = (wn * NT * 16 + fr) * RB;
     // DB: fragments of K sub-step 1 are fetched from LDS while the MFMAs of sub-step 0 run (explicit second
     // register set) and the MFMA cluster is bracketed by s_setprio -- an A/B arm, see scripts/gemm_bench.py.
     auto compute = [&](int buf) {
         const char* xs = smem + buf * STAGE + xfo;
-        const char* ws = smem + buf * STAGE + BM * 128 + wfo;
-        if constexpr (DB) {
+        const char* ws = smem + buf * STAGE + BM * RB + wfo;
+        if constexpr (RB == 64) {
+            const int co = (fq ^ ((-(fr >> 2)) & 3)) << 4;
+            uint4 xf[MT], wf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 1024 + co);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 1024 + co);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
+        } else if constexpr (DB) {
             const int co0 = ((0 * 4 + fq) ^ sw) << 4, co1 = ((1 * 4 + fq) ^ sw) << 4;
             uint4 xf0[MT], wf0[NT], xf1[MT], wf1[NT];
 #pragma unroll
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
         const int co0 = ((0 * 4 + fq) ^ sw) << 4, co1 = ((1 * 4 + fq) ^ sw) << 4;
         auto rd = [&](int buf, int co, uint4* xf, uint4* wf) {
             const char* xs = smem + buf * STAGE + xfo;
-            const char* ws = smem + buf * STAGE + BM * 128 + wfo;
+            const char* ws = smem + buf * STAGE + BM * RB + wfo;
 #pragma unroll
             for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 2048 + co);
 #pragma unroll
@@ -623,11 +638,12 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     }
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false> void launch_big(GemmKP& p, hipStream_t s) {
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    p.nkt = p.K / (RB / (int)sizeof(T));
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -696,7 +712,15 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 6;  // (fp32 256x256 spills)
         else variant = d->dtype == GP_F16 ? 7 : 4;   // 6 / 7 = software-pipelined schedule (+3..16 % in one-process A/B)
     }
-    GP_REQUIRE(variant >= 1 && variant <= 7 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    GP_REQUIRE(variant >= 1 && variant <= 9 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    if (variant == 8) {   // 256x256, 64-byte K steps, 4-stage ring (3 steps of DMA in flight)
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 9) {   // 128x128, 64-byte K steps, 4-stage ring, two workgroups per CU
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 4, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     GP_REQUIRE(!(p.gn_partial && variant == 1), "gp_gemm: fused GroupNorm needs a large-tile variant");
     if (variant == 6) {   // A/B arms: explicit fragment double buffering (f16 only; fp32 falls back to 3 / 4)
         if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);

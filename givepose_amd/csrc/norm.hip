@@ -179,6 +179,9 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
+    // bias / LN weight / LN bias (3 x C fp32) are staged in LDS once: a global load inside the slab loop would make
+    // hipcc wait vmcnt(0), i.e. for the in-flight LDS-DMA of the next slab, serialising DMA and convolution.
+    const float* par_s = reinterpret_cast<const float*>(dsm + NBUF * BUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,6 +212,14 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
     const int slot = tid & 15, pt = tid >> 4;
     const int row = pt / SPR, col0 = (pt % SPR) * PPT;
     float acc[NSLAB][PPT][VEC];
+    {
+        const int pin = (3 * C * 4 + 1023) / 1024;   // 1 KB DMA pieces of the parameter block
+        for (int ins = wave; ins < pin; ins += 8) {
+            const int f = (ins * 64 + lane) * 4;      // float index into [bias | lnw | lnb]
+            const float* src = f < C ? bias + f : (f < 2 * C ? lnw + (f - C) : (f < 3 * C ? lnb + (f - 2 * C) : reinterpret_cast<const float*>(gp_zero_page_tu)));
+            glds16_n(src, lds0 + NBUF * BUF + ins * 1024);
+        }
+    }
     if (dbg != 2) issue(0, 0);
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
         const char* w_s = in_s + IN_INSTR * 1024;
         {
             float bv[VEC];
-            load_f32<T>(bias + s * SC + slot * VEC, bv);
+            load_f32<T>(par_s + s * SC + slot * VEC, bv);
 #pragma unroll
             for (int p = 0; p < PPT; ++p)
 #pragma unroll
@@ -268,8 +279,8 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
         float gw[VEC], gb[VEC];
-        load_f32<T>(lnw + s * SC + slot * VEC, gw);
-        load_f32<T>(lnb + s * SC + slot * VEC, gb);
+        load_f32<T>(par_s + C + s * SC + slot * VEC, gw);
+        load_f32<T>(par_s + 2 * C + s * SC + slot * VEC, gb);
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
             Vec16<T> o;
@@ -284,10 +295,10 @@ template <typename T, int NSLAB>
 void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B,
                       int H, int W, int C, float eps, hipStream_t s, int dbg = 0) {
     constexpr int NPX = 14 * 14, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
-    constexpr int LDS = (NSLAB > 1 ? 2 : 1) * (IN_INSTR + W_INSTR) * 1024;
+    const int LDS = (NSLAB > 1 ? 2 : 1) * (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tiled_kernel<T, NSLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tiled_kernel<T, NSLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL((dwconv7_ln_tiled_kernel<T, NSLAB>), dim3(B * (H / 8) * (W / 8)), dim3(512), LDS, s, (const T*)x,
