@@ -141,6 +141,16 @@ def main():
             d = classes["dcnv3"]
             line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
                                        "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None}
+        # HBM traffic of the same kernels from PMC counters (collected with rocprofv3 in separate passes and
+        # committed under profiles/; bench.py itself cannot read PMCs): bytes per gp_gemm launch, FETCH_SIZE x2-corrected
+        pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if pmc and args.batch == 64 and args.dtype == "f16" and args.workload == "full":
+            t = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["classes"]
+            line["roofline"]["traffic"] = round(t["gemm"]["hbm_bytes_per_step"] / g["launches_per_step"])
+            line["roofline"]["traffic_unit"] = "HBM bytes per launch (profiles/%s); algorithmic bytes per launch = %d" % (
+                pmc[-1], round(g["gbs"] * 1e9 * g["avg_launch_us"] * 1e-6))
+            if "dcnv3" in classes and "dcnv3" in t:
+                line["roofline_gather"]["traffic"] = round(t["dcnv3"]["hbm_bytes_per_step"] / classes["dcnv3"]["launches_per_step"])
         line["kernel_classes"] = classes
         line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
 

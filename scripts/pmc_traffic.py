@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-kernel-class HBM traffic.
+
+  python scripts/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out.json>
+
+Correction (guides/MI355X_MICROARCH.md, HBM section): both counters are in KB; on gfx950 FETCH_SIZE tallies 128-B
+requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled here; WRITE_SIZE is exact.
+"""
+import collections, csv, glob, json, sys
+
+CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce")), ("dcnv3", ("dcnv3_",)),
+         ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
+         ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
+         ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
+
+
+def load(d, counter):
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            n = r["Kernel_Name"]
+            for cls, keys in CLASS:
+                if any(k in n for k in keys):
+                    out[cls][0] += 1
+                    out[cls][1] += float(r["Counter_Value"])
+                    break
+    return out
+
+
+fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+res = {}
+for cls, _ in CLASS:
+    if cls in fe and cls in wr and fe[cls][0]:
+        n = fe[cls][0]
+        rd = 2.0 * fe[cls][1] * 1024 / n          # gfx950 correction: x2
+        wb = wr[cls][1] * 1024 / wr[cls][0]
+        res[cls] = {"launches_profiled": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb,
+                    "hbm_bytes_per_launch": rd + wb}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph, bs=64 fp16",
+           "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "classes": res},
+          open(sys.argv[3], "w"), indent=1)
+print(json.dumps(res, indent=1))
