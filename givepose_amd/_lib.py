@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgivepose_hip.so")
 
 GP_F32, GP_F16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
-EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU = 0, 1, 2, 3, 4, 5
 KC_GEMM, KC_DCNV3, KC_DWCONV_LN, KC_NORM, KC_ELEMENTWISE, KC_SMALL, KC_COUNT = 0, 1, 2, 3, 4, 5, 6
 KC_NAMES = ["gemm", "dcnv3", "dwconv_ln", "norm", "elementwise", "small"]
 
@@ -49,6 +49,8 @@ PROTOTYPES = {
     "gp_xyz_conv3x3_s2": ([_P] * 3 + [c_int] * 4 + [_P], c_int),
     "gp_size_head": ([_P] * 8 + [c_int] * 5 + [_P], c_int),
     "gp_pose_tail": ([_P, _P, c_int] + [_P] * 10 + [c_int, c_int] + [_P] * 5 + [c_int, _P], c_int),
+    "gp_resnet_stem": ([_P] * 4 + [c_int] * 4 + [_P], c_int),
+    "gp_maxpool3x3s2": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_mask_resize_nearest": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "gp_graph_begin": ([_P], c_int),
     "gp_graph_end": ([_P, POINTER(c_void_p)], c_int),

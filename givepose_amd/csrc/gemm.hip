@@ -53,6 +53,11 @@ __device__ __forceinline__ void epi_store(const GemmKP& p, int m, int n, f32x4 v
         case GP_EPI_LRELU:
             for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.1f * v[j];
             break;
+        case GP_EPI_RES_RELU: {
+            const T* r = reinterpret_cast<const T*>(p.res) + (long)m * p.ldres + n;
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf((float)r[j] + v[j], 0.0f);
+            break;
+        }
         case GP_EPI_SCALE_RES: {
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + n);
             const T* r = reinterpret_cast<const T*>(p.res) + (long)m * p.ldres + n;
@@ -109,6 +114,9 @@ __device__ __forceinline__ f32x4 epi_apply(int epi, f32x4 v, const f32x4& b, con
             break;
         case GP_EPI_SCALE_RES:
             for (int j = 0; j < 4; ++j) v[j] = (float)r[j] + g[j] * v[j];
+            break;
+        case GP_EPI_RES_RELU:
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf((float)r[j] + v[j], 0.0f);
             break;
         default: break;
     }
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmKP p) {
         for (int nt = 0; nt < 4; ++nt) {
             const int m = m0 + wm * 64 + mt * 16 + fr, n = n0 + wn * 64 + nt * 16 + fq * 4;
             for (int j = 0; j < 4; ++j) r4[mt][nt][j] = 0;
-            if (p.epi == GP_EPI_SCALE_RES && m < p.M && n < p.N) r4[mt][nt] = load_res4<T>(p, m, n);
+            if ((p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) && m < p.M && n < p.N) r4[mt][nt] = load_res4<T>(p, m, n);
         }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -572,8 +580,8 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     const bool nok = en < p.N;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
-    const bool sres = p.epi == GP_EPI_SCALE_RES;
-    const f32x4 g4 = (sres && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
+    const bool sres = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
+    const f32x4 g4 = (p.epi == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
     constexpr bool PRE = sizeof(T) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
     typename Res4<T>::type r4[PRE ? MT / 2 : 1][8];
     if (PRE) {
@@ -658,9 +666,10 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(d->N % 4 == 0, "gp_gemm: N=%d must be a multiple of 4", d->N);
     GP_REQUIRE(d->K % KPT == 0, "gp_gemm: K=%d must be a multiple of %d", d->K, KPT);
     GP_REQUIRE(d->ldc % 4 == 0 && d->ldc >= d->N, "gp_gemm: ldc=%d invalid", d->ldc);
-    GP_REQUIRE(d->epilogue >= GP_EPI_NONE && d->epilogue <= GP_EPI_SCALE_RES, "gp_gemm: bad epilogue");
-    if (d->epilogue == GP_EPI_SCALE_RES)
-        GP_REQUIRE(d->gamma && d->residual && d->ldres % 4 == 0 && d->ldres >= d->N, "gp_gemm: SCALE_RES needs gamma/residual");
+    GP_REQUIRE(d->epilogue >= GP_EPI_NONE && d->epilogue <= GP_EPI_RES_RELU, "gp_gemm: bad epilogue");
+    if (d->epilogue == GP_EPI_SCALE_RES) GP_REQUIRE(d->gamma != nullptr, "gp_gemm: SCALE_RES needs gamma");
+    if (d->epilogue == GP_EPI_SCALE_RES || d->epilogue == GP_EPI_RES_RELU)
+        GP_REQUIRE(d->residual && d->ldres % 4 == 0 && d->ldres >= d->N, "gp_gemm: epilogue needs a residual");
     GemmKP p;
     memset(&p, 0, sizeof(p));
     p.X = d->X; p.W = d->W; p.bias = d->bias; p.gamma = d->gamma; p.res = d->residual; p.C = d->C; p.ws = d->workspace;
@@ -698,7 +707,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     const double flops = 2.0 * d->M * d->N * d->K;
     const double xbytes = d->KH > 0 ? (double)d->B * d->H * d->Win * d->Cin * esz : (double)d->M * d->K * esz;
     const double bytes = xbytes + (double)d->N * d->K * esz + (double)d->M * d->N * (d->out_f32 ? 4 : esz) +
-                         (d->epilogue == GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
+                         (d->epilogue >= GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
     // variant: 1 = 128x128 register-staged (+split-K), 2 = 256x128 LDS-DMA, 3 = 256x256 LDS-DMA, 0 = pick
     int variant = d->variant % 10;

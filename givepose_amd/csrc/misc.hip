@@ -228,6 +228,85 @@ __global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------- ResNet stem / maxpool
+// conv7x7 s2 p3 (3 -> 64, BN folded) + ReLU.  Block = 64 output pixels of one output row: the 7 x 133 x 3 input
+// patch and the 147 x 64 filter bank are staged in LDS; thread = 4 output channels x 4 pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void resnet_stem_kernel(const float* __restrict__ img, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias, T* __restrict__ out, int H,
+                                                          int W) {
+    constexpr int PXB = 64, IWD = 2 * PXB + 5;
+    __shared__ __attribute__((aligned(16))) float w_s[147 * 64];
+    __shared__ float in_s[3][7][IWD + 1];
+    const int Ho = H / 2, Wo = W / 2, nwb = Wo / PXB;
+    const int wblk = blockIdx.x % nwb, ho = (blockIdx.x / nwb) % Ho, b = blockIdx.x / (nwb * Ho);
+    const int wo0 = wblk * PXB, tid = threadIdx.x;
+    for (int i = tid; i < 147 * 64; i += 256) w_s[i] = wt[i];
+    for (int i = tid; i < 3 * 7 * IWD; i += 256) {
+        const int c = i / (7 * IWD), r = (i / IWD) % 7, x = i % IWD;
+        const int hi = ho * 2 - 3 + r, wi = wo0 * 2 - 3 + x;
+        in_s[c][r][x] = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? img[(((long)b * 3 + c) * H + hi) * W + wi] : 0.f;
+    }
+    __syncthreads();
+    const int cq = tid & 15, pt = tid >> 4;
+    float acc[4][4];
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[p][e] = bv[e];
+    for (int c = 0; c < 3; ++c)
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + ((c * 7 + kh) * 7 + kw) * 64 + cq * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float v = in_s[c][kh][(pt * 4 + p) * 2 + kw];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[p][e] = fmaf(v, wv[e], acc[p][e]);
+                }
+            }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        T* o = out + (((long)b * Ho + ho) * Wo + wo0 + pt * 4 + p) * 64 + cq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_T(o + e, fmaxf(acc[p][e], 0.f));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                           int W, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const int CT = C / VEC, Ho = H / 2, Wo = W / 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * Ho * Wo * CT) return;
+    const int cs = (int)(idx % CT);
+    long t = idx / CT;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const Vec16<T> v = load16<T>(x + ((b * H + iy) * W + ix) * C + cs * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], v.get(e));
+        }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, m[e]);
+    store16<T>(y + ((b * Ho + oy) * Wo + ox) * C + cs * VEC, o);
+}
+
 // ------------------------------------------------------------------------------------- SizeHead
 // kernel 1: grid (B, F/16): global max over HW -> LDS, then 16 hidden units (BN folded, ReLU) -> scratch (B,F)
 template <typename T>
@@ -485,6 +564,33 @@ extern "C" int gp_pose_tail(const float* h, const float* hz, int ldh, const floa
     hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(64), 0, s, h, hz, ldh, w_r, b_r, w_t, b_t, w_z, b_z, cam_K,
                        bbox_center, resize_ratio, roi_wh, wild6d, site_centroid, rot6d, pred_t, rot_allo, rot_ego, trans);
     GP_LAUNCH_CHECK("gp_pose_tail");
+}
+
+extern "C" int gp_resnet_stem(const float* img, const float* w, const float* b, void* out, int B, int H, int W, int dtype,
+                              void* stream) {
+    GP_REQUIRE(img && w && b && out && B > 0, "gp_resnet_stem: bad argument");
+    GP_DT_OK(dtype);
+    GP_REQUIRE(H % 2 == 0 && W % 128 == 0, "gp_resnet_stem: H,W=%d,%d must be multiples of 2,128", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const long px = (long)B * (H / 2) * (W / 2);
+    gp_timing_before(s, GP_KC_SMALL, 2.0 * px * 147 * 64, (double)B * 3 * H * W * 4 + (double)px * 64 * (dtype == GP_F16 ? 2 : 4));
+    dim3 grid(B * (H / 2) * (W / 2 / 64));
+    if (dtype == GP_F16) hipLaunchKernelGGL(resnet_stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, (half_t*)out, H, W);
+    else hipLaunchKernelGGL(resnet_stem_kernel<float>, grid, dim3(256), 0, s, img, w, b, (float*)out, H, W);
+    GP_LAUNCH_CHECK("gp_resnet_stem");
+}
+
+extern "C" int gp_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    GP_REQUIRE(x && y && B > 0 && H % 2 == 0 && W % 2 == 0, "gp_maxpool3x3s2: bad argument");
+    GP_DT_OK(dtype);
+    const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
+    GP_REQUIRE(C % vec == 0, "gp_maxpool3x3s2: C=%d", C);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * (H / 2) * (W / 2) * (C / vec);
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 0.0, (double)B * H * W * C * esz * 1.25);
+    if (dtype == GP_F16) hipLaunchKernelGGL(maxpool3x3s2_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, B, H, W, C);
+    else hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
+    GP_LAUNCH_CHECK("gp_maxpool3x3s2");
 }
 
 extern "C" int gp_mask_resize_nearest(const float* mask, float* out, int B, int S, int R, void* stream) {

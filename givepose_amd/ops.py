@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_RELU,
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_RELU, EPI_RES_RELU,
                    EPI_SCALE_RES, GP_F16, GP_F32, GemmDesc, check)
 
 __all__ = ["dtype_code", "gemm", "conv2d_nhwc", "dcnv3_forward", "dcnv3_forward_into", "convnext_stem", "dwconv_ln",
@@ -118,7 +118,8 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     return out
 
 
-def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None):
+def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None,
+                residual=None):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -126,6 +127,7 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
     if out is None:
         out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
+         residual=None if residual is None else residual.view(B * Ho * Wo, -1),
          conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn)
     return out
 
@@ -257,6 +259,19 @@ def pose_tail(h, hz, ldh, W, cam_K, bbox_center, resize_ratio, roi_wh, wild6d, s
                             _ptr(W["fc_z.w"]), _ptr(W["fc_z.b"]), _ptr(cam_K), _ptr(bbox_center), _ptr(resize_ratio),
                             _ptr(roi_wh), int(wild6d), int(site), _ptr(outs["rot6d"]), _ptr(outs["pred_t"]),
                             _ptr(outs["rot_allo"]), _ptr(outs["rot_ego"]), _ptr(outs["trans"]), B, _stream()), "gp_pose_tail")
+
+
+def resnet_stem(img, w, b, out):
+    B, _, H, W_ = img.shape
+    check(_L().gp_resnet_stem(_ptr(_contig(_chk(img, "img", torch.float32), "img")), _ptr(w), _ptr(b), _ptr(out), B, H, W_,
+                              dtype_code(out.dtype), _stream()), "gp_resnet_stem")
+    return out
+
+
+def maxpool3x3s2(x, out):
+    B, H, W_, C = x.shape
+    check(_L().gp_maxpool3x3s2(_ptr(_contig(x, "x")), _ptr(out), B, H, W_, C, dtype_code(x.dtype), _stream()), "gp_maxpool3x3s2")
+    return out
 
 
 def mask_resize_nearest(mask, out):

@@ -46,8 +46,10 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 class PoseNet(nn.Module):
     def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None):
         super().__init__()
-        if cfg.main_backbone != "convnext":
-            raise NotImplementedError("reference PoseNet asserts backbone == 'convnext' (network/PoseNet.py:142)")
+        # the reference asserts backbone == 'convnext' (network/PoseNet.py:142); 'resnet34' (network/resnet.py:167-176,
+        # defined but never wired there) is this build's throughput variant with feature_channel 512
+        if cfg.main_backbone not in ("convnext", "resnet34"):
+            raise NotImplementedError(f"unknown backbone {cfg.main_backbone}")
         self.cfg = cfg
         self.compute_dtype = dtype
         self.use_graph = use_graph
@@ -96,9 +98,25 @@ class PoseNet(nn.Module):
         W = {}
         cfg = self.cfg
         g = lambda k: sd["backbone." + k]
-        W["stem.w"], W["stem.b"] = f32(g("stem_0.weight").reshape(-1, 48).t()), f32(g("stem_0.bias"))
-        W["stem.ln_w"], W["stem.ln_b"] = f32(g("stem_1.weight")), f32(g("stem_1.bias"))
-        for s, (d, n) in enumerate(zip(cfg.convnext_dims, cfg.convnext_depths)):
+        if cfg.main_backbone == "resnet34":
+            def fold(conv, bn):      # eval BatchNorm folded into the conv: w' = w * s[co], b' = beta - mean * s
+                sc = g(bn + ".weight") / torch.sqrt(g(bn + ".running_var") + 1e-5)
+                return g(conv + ".weight") * sc[:, None, None, None], g(bn + ".bias") - g(bn + ".running_mean") * sc
+            w, b = fold("conv1", "bn1")
+            W["rs.stem_w"], W["rs.stem_b"] = f32(w.reshape(64, 147).t()), f32(b)
+            for li, (planes, blocks, stride) in enumerate(synth.RESNET34_LAYERS, 1):
+                for bi in range(blocks):
+                    p, q = f"layer{li}.{bi}", f"rs{li}.{bi}."
+                    for c in ("1", "2"):
+                        w, b = fold(p + ".conv" + c, p + ".bn" + c)
+                        W[q + "w" + c], W[q + "b" + c] = lowp(w.permute(0, 2, 3, 1).reshape(planes, -1)), f32(b)
+                    if ("backbone." + p + ".downsample.0.weight") in sd:
+                        w, b = fold(p + ".downsample.0", p + ".downsample.1")
+                        W[q + "wd"], W[q + "bd"] = lowp(w.reshape(planes, -1)), f32(b)
+        for s, (d, n) in enumerate(zip(cfg.convnext_dims, cfg.convnext_depths) if cfg.main_backbone == "convnext" else ()):
+            if s == 0:
+                W["stem.w"], W["stem.b"] = f32(g("stem_0.weight").reshape(-1, 48).t()), f32(g("stem_0.bias"))
+                W["stem.ln_w"], W["stem.ln_b"] = f32(g("stem_1.weight")), f32(g("stem_1.bias"))
             if s > 0:
                 p = f"stages_{s}.downsample."
                 W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"] = f32(g(p + "0.weight")), f32(g(p + "0.bias"))
@@ -176,8 +194,14 @@ class PoseNet(nn.Module):
         buf["roi_coord_2d"], buf["cam_K"], buf["roi_wh"] = f(B, 2, R, R), f(B, 3, 3), f(B, 2)
         buf["bbox_center"], buf["resize_ratio"], buf["mean_size"] = f(B, 2), f(B), f(B, 3)
         # trunk
-        dims = cfg.convnext_dims
+        dims = cfg.convnext_dims if cfg.main_backbone == "convnext" else ()
         H = S // 4
+        if cfg.main_backbone == "resnet34":
+            buf["rs_stem"] = e(B, S // 2, S // 2, 64)
+            for li, (planes, _, _) in enumerate(synth.RESNET34_LAYERS, 1):
+                h = S // (2 << li)          # 64, 32, 16, 8
+                for n in ("a", "b", "c"):    # block input/output ping-pong + conv1 output
+                    buf[f"rs{li}{n}"] = e(B, h, h, planes)
         for s, d in enumerate(dims):
             h = H >> s
             buf[f"x{s}"] = e(B, h, h, d)
@@ -236,12 +260,36 @@ class PoseNet(nn.Module):
             cur = dst
         ops.xyz_out_layer(cur.view(B, r * r, 256), W[head + ".out_w"], W[head + ".out_b"], out_nchw, out_nhwc4)
 
+    def _resnet34(self, W, buf):
+        """network/resnet.py:137-147 (ResNet.forward up to layer4), BasicBlock :38-52; eval BatchNorm folded into the
+        convs, ReLU / residual+ReLU fused into the implicit-GEMM epilogues.  Returns (B,8,8,512)."""
+        from ._lib import EPI_RELU, EPI_RES_RELU
+        s = ops.resnet_stem(buf["roi_img"], W["rs.stem_w"], W["rs.stem_b"], buf["rs_stem"])
+        x = ops.maxpool3x3s2(s, buf["rs1a"])
+        for li, (planes, blocks, stride) in enumerate(synth.RESNET34_LAYERS, 1):
+            for bi in range(blocks):
+                q = f"rs{li}.{bi}."
+                st = stride if bi == 0 else 1
+                out = buf[f"rs{li}b"] if x is buf[f"rs{li}a"] or li > 1 and bi == 0 else buf[f"rs{li}a"]
+                h = ops.conv2d_nhwc(x, W[q + "w1"], 3, 3, st, 1, out=buf[f"rs{li}c"], bias=W[q + "b1"], epilogue=EPI_RELU)
+                if (q + "wd") in W:
+                    res = ops.conv2d_nhwc(x, W[q + "wd"], 1, 1, st, 0, out=buf[f"rs{li}a"], bias=W[q + "bd"])
+                    out = buf[f"rs{li}b"]
+                else:
+                    res = x
+                x = ops.conv2d_nhwc(h, W[q + "w2"], 3, 3, 1, 1, out=out, bias=W[q + "b2"], epilogue=EPI_RES_RELU, residual=res)
+        return x
+
     def _launch_all(self, B, plan):
         W, buf, cfg = self._packed, plan["buf"], self.cfg
         dims, depths = cfg.convnext_dims, cfg.convnext_depths
         ops.mask_resize_nearest(buf["roi_mask"], buf["mask_out"])
-        # ---- ConvNeXt trunk (network/backbone.py:36-46)
-        x = ops.convnext_stem(buf["roi_img"], W["stem.w"], W["stem.b"], W["stem.ln_w"], W["stem.ln_b"], buf["x0"])
+        if cfg.main_backbone == "resnet34":
+            feat = self._resnet34(W, buf)
+            dims, depths = (512,), ()
+        else:
+            # ---- ConvNeXt trunk (network/backbone.py:36-46)
+            x = ops.convnext_stem(buf["roi_img"], W["stem.w"], W["stem.b"], W["stem.ln_w"], W["stem.ln_b"], buf["x0"])
         for s, (d, n) in enumerate(zip(dims, depths)):
             if s > 0:
                 t = ops.layernorm(x, W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"], buf[f"dsn{s}"])
@@ -253,7 +301,8 @@ class PoseNet(nn.Module):
                 ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU)
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
                          gamma=W[q + "gamma"], residual=x2d)
-        feat = x                                    # (B,8,8,1024)
+        if cfg.main_backbone == "convnext":
+            feat = x                                # (B,8,8,1024)
         fc = dims[-1]
         feat2d = feat.view(B * 64, fc)
         ops.size_head(feat.view(B, 64, fc), W["size.w1"], W["size.b1"], W["size.w2"], W["size.b2"], buf["mean_size"], buf["size"], buf["size_scratch"])
@@ -359,7 +408,7 @@ class PoseNet(nn.Module):
             cur.wait_stream(run_stream)
         return {"rot": buf["rot_ego"].view(B, 3, 3), "trans": buf["trans"], "size": buf["size"], "mask": buf["mask_out"],
                 "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
-                "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf[f"x{len(self.cfg.convnext_dims) - 1}"],
+                "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf.get(f"x{len(self.cfg.convnext_dims) - 1}"),
                 "feat_cat": buf["feat_cat"]}
 
     def static_inputs(self, B, device="cuda"):

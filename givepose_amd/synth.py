@@ -53,6 +53,32 @@ def _convnext_manifest(cfg, m):
             m[p + ".mlp.fc2.bias"] = (d,)
 
 
+RESNET34_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))   # (planes, blocks, stride) network/resnet.py:167-176
+
+
+def _bn_manifest(prefix, c, m):
+    for k, shp in (("weight", (c,)), ("bias", (c,)), ("running_mean", (c,)), ("running_var", (c,)), ("num_batches_tracked", ())):
+        m[f"{prefix}.{k}"] = shp
+
+
+def _resnet34_manifest(m):
+    """network/resnet.py:121-152 (ResNet(BasicBlock,[3,4,6,3]) without avgpool/fc)."""
+    m["backbone.conv1.weight"] = (64, 3, 7, 7)
+    _bn_manifest("backbone.bn1", 64, m)
+    inpl = 64
+    for li, (planes, blocks, stride) in enumerate(RESNET34_LAYERS, 1):
+        for b in range(blocks):
+            p = f"backbone.layer{li}.{b}"
+            m[p + ".conv1.weight"] = (planes, inpl if b == 0 else planes, 3, 3)
+            _bn_manifest(p + ".bn1", planes, m)
+            m[p + ".conv2.weight"] = (planes, planes, 3, 3)
+            _bn_manifest(p + ".bn2", planes, m)
+            if b == 0 and (stride != 1 or inpl != planes):
+                m[p + ".downsample.0.weight"] = (planes, inpl, 1, 1)
+                _bn_manifest(p + ".downsample.1", planes, m)
+        inpl = planes
+
+
 def _xyz_head_manifest(prefix, in_dim, m):
     m[f"{prefix}.features.0.weight"] = (in_dim, 256, 3, 3)  # ConvTranspose2d [Cin, Cout, kh, kw]
     m[f"{prefix}.features.1.weight"] = (256,)
@@ -69,8 +95,12 @@ def _xyz_head_manifest(prefix, in_dim, m):
 def param_manifest(cfg: PoseNetConfig = PoseNetConfig()):
     """OrderedDict name -> shape, reference state_dict order (backbone first)."""
     m = OrderedDict()
-    assert cfg.main_backbone == "convnext", "param_manifest covers the reference-wired ConvNeXt path"
-    _convnext_manifest(cfg, m)
+    if cfg.main_backbone == "convnext":
+        _convnext_manifest(cfg, m)
+    elif cfg.main_backbone == "resnet34":   # throughput variant, not wired by the reference (SURVEY.md 0.2)
+        _resnet34_manifest(m)
+    else:
+        raise ValueError(cfg.main_backbone)
     fc = cfg.feature_channel
     _xyz_head_manifest("xyz_nocs_head", fc, m)
     m["size_head.conv1.weight"] = (cfg.feat_ts, fc, 1)
@@ -158,6 +188,8 @@ def synth_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
     if name.endswith(".gamma"):                      # ConvNeXt layer scale
         return r.uniform(0.1, 0.3, shape).astype(np.float32)
+    if re.search(r"backbone\.layer\d\.\d+\.bn2\.weight$", name):   # keep 16 residual adds from blowing up
+        return (0.25 + 0.05 * r.standard_normal(shape)).astype(np.float32)
     if len(shape) == 1:
         if name.endswith(".weight"):                 # norm scales
             return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)

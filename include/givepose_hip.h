@@ -32,7 +32,8 @@ enum gp_epilogue {
     GP_EPI_GELU = 1,      /* out = gelu_erf(v)                              */
     GP_EPI_RELU = 2,      /* out = max(v, 0)                                */
     GP_EPI_LRELU = 3,     /* out = v > 0 ? v : 0.1 v                        */
-    GP_EPI_SCALE_RES = 4  /* out = residual + gamma[n] * v  (ConvNeXt block) */
+    GP_EPI_SCALE_RES = 4, /* out = residual + gamma[n] * v  (ConvNeXt block) */
+    GP_EPI_RES_RELU = 5   /* out = max(residual + v, 0)    (ResNet BasicBlock, network/resnet.py:49-52) */
 };
 
 const char* gp_last_error(void);
@@ -173,6 +174,13 @@ int gp_pose_tail(const float* h, const float* hz, int ldh, const float* w_r, con
                  const float* bbox_center, const float* resize_ratio, const float* roi_wh, int wild6d,
                  int site_centroid, float* rot6d, float* pred_t, float* rot_allo, float* rot_ego,
                  float* trans, int B, void* stream);
+
+/* ResNet stem (network/resnet.py:137-141): Conv2d(3,64,7,s2,p3,bias=False) + eval BatchNorm (folded by the host into
+ * w / b) + ReLU on the NCHW fp32 image -> (B,H/2,W/2,64) channels-last.  w: (147, 64) fp32 tap-major, k = c*49+kh*7+kw. */
+int gp_resnet_stem(const float* img, const float* w, const float* b, void* out, int B, int H, int W, int dtype,
+                   void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1), channels-last (network/resnet.py:140). */
+int gp_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 /* torchvision Resize(out, NEAREST) on a square fp32 mask (B,1,S,S) -> (B,1,R,R) (PoseNet.py:170,180). */
 int gp_mask_resize_nearest(const float* mask, float* out, int B, int S, int R, void* stream);

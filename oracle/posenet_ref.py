@@ -103,6 +103,26 @@ def convnext_ref(P, img, cfg, prefix="backbone."):
     return [x]
 
 
+def resnet34_ref(P, img, prefix="backbone."):
+    """network/resnet.py:137-147 (ResNet.forward up to layer4) with BasicBlock :24-52, eval BatchNorm.
+    Returns [ (B,512,H/32,W/32) ]."""
+    def bn(x, p):
+        return F.batch_norm(x, P[p + ".running_mean"], P[p + ".running_var"], P[p + ".weight"], P[p + ".bias"], False, 0.0, 1e-5)
+    x = F.relu(bn(F.conv2d(img, P[prefix + "conv1.weight"], None, stride=2, padding=3), prefix + "bn1"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, (planes, blocks, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), 1):
+        for b in range(blocks):
+            p = f"{prefix}layer{li}.{b}"
+            s = stride if b == 0 else 1
+            out = F.relu(bn(F.conv2d(x, P[p + ".conv1.weight"], None, stride=s, padding=1), p + ".bn1"))
+            out = bn(F.conv2d(out, P[p + ".conv2.weight"], None, padding=1), p + ".bn2")
+            res = x
+            if (p + ".downsample.0.weight") in P:
+                res = bn(F.conv2d(x, P[p + ".downsample.0.weight"], None, stride=s), p + ".downsample.1")
+            x = F.relu(out + res)
+    return [x]
+
+
 def size_head_ref(P, feat, prefix="size_head."):
     """network/pose_head.py:30-42 (eval: BN uses running stats, dropout is identity)."""
     x = feat.flatten(2, 3).max(dim=-1, keepdim=True).values
@@ -236,7 +256,7 @@ def posenet_forward_ref(P, data, cfg, return_intermediates=False):
     f = lambda k: data[k].to(dt)
     img = f("roi_img")
     mask_out = data["roi_mask"][..., :: cfg.img_size // cfg.out_res, :: cfg.img_size // cfg.out_res]  # Resize NEAREST :170,180
-    feat = convnext_ref(P, img, cfg)
+    feat = convnext_ref(P, img, cfg) if cfg.main_backbone == "convnext" else resnet34_ref(P, img)
     pred_size = size_head_ref(P, feat[0])
     nocs = xyz_head_ref(P, feat[0], "xyz_nocs_head.")
     nocs_feat = map_encoder_ref(P, nocs, cfg)

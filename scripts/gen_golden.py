@@ -243,8 +243,29 @@ def gen_e2e():
              **{"mid_" + k: v for k, v in inter.items()})
 
 
+def gen_resnet():
+    """network/resnet.py resnet34 trunk (conv1..layer4 in the order of ResNet.forward :137-147; avgpool/fc dropped:
+    SURVEY.md 8a row a14).  The class is pure torch, so it is the reference's own arithmetic."""
+    from network.resnet import resnet34
+    print("resnet34 trunk")
+    cfg = PoseNetConfig(main_backbone="resnet34")
+    m = resnet34().eval()
+    load_synth_into(m, "backbone.", rename=lambda k: None if k.startswith("fc.") else k)
+    r = np.random.Generator(np.random.Philox(key=[SEED, 34]))
+    x = torch.from_numpy(r.standard_normal((2, 3, 128, 128), dtype=np.float32))
+    y = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+    y = m.layer4(m.layer3(m.layer2(m.layer1(y))))
+    Pn = O.load_params(synth.synth_state_dict(cfg, SEED))
+    d = maxdiff(y, O.resnet34_ref(Pn, x)[0])
+    print(f"  oracle vs reference {d:.2e} |out| {float(y.abs().mean()):.3f} max {float(y.abs().max()):.2f}")
+    assert d < 1e-4
+    save("resnet34_trunk", x=x, expected=y)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["core", "modules", "e2e"]
+    which = sys.argv[1:] or ["core", "modules", "e2e", "resnet"]
+    if "resnet" in which:
+        gen_resnet()
     if "core" in which:
         gen_dcnv3_core()
     if "modules" in which:

@@ -117,3 +117,20 @@ def test_state_dict_contract(golden):
     assert [k for k in sd if not k.startswith("backbone.")] == list(ref)
     assert all(list(sd[k].shape) == ref[k] for k in ref)
     net.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 5e-2)])
+def test_resnet34_variant_matches_oracle(dtype, tol):
+    """a14 / BASELINE configs 1-2: ResNet-34 trunk (network/resnet.py:167-176, pinned by tests/golden/resnet34_trunk.npz
+    through the oracle) + the same heads with feature_channel 512 -- the build's own wiring."""
+    from givepose_amd import synth
+    from givepose_amd.config import PoseNetConfig
+    from oracle import posenet_ref as O
+    cfg = PoseNetConfig(main_backbone="resnet34")
+    net = _model(dtype, main_backbone="resnet34")
+    data = _batch(3, 17)
+    ref = O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg)
+    out = net(data, "cuda")
+    err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    print("resnet34", dtype, err)
+    assert all(v < tol for v in err.values()), err

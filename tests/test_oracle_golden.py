@@ -99,3 +99,11 @@ def test_posenet_e2e_B1(golden, params):
     for k, tol in (("rot", 1e-4), ("trans", 1e-4), ("size", 1e-4), ("nocs_coor", 1e-4), ("ivfc_coor", 1e-4)):
         assert np.abs(out[k].numpy() - z["out_" + k]).max() < tol, k
     assert np.abs(out["feat"].numpy() - z["mid_feat"]).max() < 1e-4
+
+
+def test_resnet34_trunk(golden):
+    """a14: the oracle trunk vs the reference's own resnet34 class (network/resnet.py) on seeded weights."""
+    z = golden("resnet34_trunk")
+    P = O.load_params(synth.synth_state_dict(PoseNetConfig(main_backbone="resnet34"), 0))
+    got = O.resnet34_ref(P, T(z["x"]))[0].numpy()
+    assert np.abs(got - z["expected"]).max() < 1e-4
