@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_CROP = {"full": 67.517, "nodcn": 66.506, "resnet34": 36.81, "resnet34_nodcn": 35.80}
+GFLOP_PER_CROP = {"full": 67.517, "nodcn": 66.506, "resnet34": 36.81, "resnet34_nodcn": 35.80, "att": 66.43}
 GATHER_MB_PER_CROP = 3.74
 PEAK_F16_TFLOPS = 2500.0                                 # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
-    ap.add_argument("--workload", default="full", choices=["full", "nodcn", "resnet34", "resnet34_nodcn"],
+    ap.add_argument("--workload", default="full", choices=["full", "nodcn", "resnet34", "resnet34_nodcn", "att"],
                     help="full = reference wiring (ConvNeXt-B + DCNv3, BASELINE configs[2]); nodcn = use_dcn=''; "
                          "resnet34[_nodcn] = BASELINE configs[0-1] read literally (ResNet-34 trunk, not wired by the reference)")
     ap.add_argument("--no-graph", action="store_true")
@@ -61,7 +61,8 @@ def main():
     B = args.batch
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     cfg = PoseNetConfig(use_dcn="" if args.workload.endswith("nodcn") else "dcnv3",
-                        main_backbone="resnet34" if args.workload.startswith("resnet34") else "convnext")
+                        main_backbone="resnet34" if args.workload.startswith("resnet34") else "convnext",
+                        nocsmap_encoder="att" if args.workload == "att" else "conv")   # att = BASELINE configs[3] in-repo analogue
     net = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph).to(dev)
     static = net.static_inputs(B, dev)
     host = synth.synth_batch(B, seed=1000 + rank)
@@ -105,7 +106,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("PoseNet.forward: " + ("ResNet-34" if args.workload.startswith("resnet34") else "ConvNeXt-B")
                                 + " trunk + SizeHead + NOCS TopDownXyzHead + "
-                                + ("plain-conv MAPEncoder (use_dcn='')" if args.workload.endswith("nodcn") else "DCNv3 MAPEncoder")
+                                + ("plain-conv MAPEncoder (use_dcn='')" if args.workload.endswith("nodcn") else
+                                   "MAPTransformerEncoer (64-token attention)" if args.workload == "att" else "DCNv3 MAPEncoder")
                                 + " + IVFC TopDownXyzHead + ConvPnPNet + pose decode (BASELINE configs[2]; the reference wires "
                                   "ConvNeXt-B, not ResNet-34: SURVEY.md 0.2)"),
                    "batch_per_gpu": B, "global_batch": world * B, "img": "256x256", "parallelism": f"dp{world}",

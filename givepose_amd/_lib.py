@@ -37,7 +37,7 @@ PROTOTYPES = {
     "gp_gemm": ([POINTER(GemmDesc), _P], c_int),
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
     "gp_dwconv_ln": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, c_long, c_int, _P], c_int),
-    "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, _P], c_int),
+    "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, c_int, _P], c_int),
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),
     "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 4 + [_P], c_int),
@@ -49,6 +49,8 @@ PROTOTYPES = {
     "gp_xyz_conv3x3_s2": ([_P] * 3 + [c_int] * 4 + [_P], c_int),
     "gp_size_head": ([_P] * 8 + [c_int] * 5 + [_P], c_int),
     "gp_pose_tail": ([_P, _P, c_int] + [_P] * 10 + [c_int, c_int] + [_P] * 5 + [c_int, _P], c_int),
+    "gp_patchify_xyz": ([_P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "gp_attention64": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "gp_resnet_stem": ([_P] * 4 + [c_int] * 4 + [_P], c_int),
     "gp_maxpool3x3s2": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_mask_resize_nearest": ([_P, _P, c_int, c_int, c_int, _P], c_int),

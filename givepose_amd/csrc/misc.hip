@@ -228,6 +228,70 @@ __global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __
     }
 }
 
+// ------------------------------------------------------------------------------------- ViT-style map encoder pieces
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ xyz4, T* __restrict__ out, int B, int R,
+                                                       int P) {
+    const int K = P * P * 3, np = R / P;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * np * np * P * P) return;
+    const int pp = (int)(idx % (P * P));
+    long t = idx / (P * P);
+    const int px = (int)(t % np); t /= np;
+    const int py = (int)(t % np);
+    const long b = t / np;
+    const int ky = pp / P, kx = pp - ky * P;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + py * P + ky) * R + px * P + kx) * 4);
+    T* o = out + ((b * np + py) * np + px) * K + pp * 3;
+    store_T(o, v[0]); store_T(o + 1, v[1]); store_T(o + 2, v[2]);
+}
+
+// one wavefront per (batch, head); lane = query token.  K and V of the head are staged in LDS as fp32; each lane
+// keeps its 64 scores in registers (two-pass softmax), so nothing but q/k/v/out touches memory.
+template <typename T>
+__global__ __launch_bounds__(64) void attention64_kernel(const T* __restrict__ qkv, T* __restrict__ out, int heads) {
+    __shared__ float ks[64][33], vs[64][33];
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads, i = threadIdx.x;
+    const int C3 = 3 * heads * 32, C = heads * 32;
+    const T* row = qkv + ((long)b * 64 + i) * C3 + h * 32;
+    float q[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+        q[d] = (float)row[d] * 0.17677669529663687f;   // head_dim ** -0.5
+        ks[i][d] = (float)row[C + d];
+        vs[i][d] = (float)row[2 * C + d];
+    }
+    __syncthreads();
+    float s[64], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) a = fmaf(q[d], ks[j][d], a);
+        s[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        s[j] = expf(s[j] - mx);
+        sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float pj = s[j] * inv;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] = fmaf(pj, vs[j][d], o[d]);
+    }
+    T* orow = out + ((long)b * 64 + i) * C + h * 32;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) store_T(orow + d, o[d]);
+}
+
 // ------------------------------------------------------------------------------------- ResNet stem / maxpool
 // conv7x7 s2 p3 (3 -> 64, BN folded) + ReLU.  Block = 64 output pixels of one output row: the 7 x 133 x 3 input
 // patch and the 147 x 64 filter bank are staged in LDS; thread = 4 output channels x 4 pixels.
@@ -564,6 +628,27 @@ extern "C" int gp_pose_tail(const float* h, const float* hz, int ldh, const floa
     hipLaunchKernelGGL(pose_tail_kernel, dim3(B), dim3(64), 0, s, h, hz, ldh, w_r, b_r, w_t, b_t, w_z, b_z, cam_K,
                        bbox_center, resize_ratio, roi_wh, wild6d, site_centroid, rot6d, pred_t, rot_allo, rot_ego, trans);
     GP_LAUNCH_CHECK("gp_pose_tail");
+}
+
+extern "C" int gp_patchify_xyz(const float* xyz4, void* out, int B, int R, int P, int dtype, void* stream) {
+    GP_REQUIRE(xyz4 && out && B > 0 && P > 0 && R % P == 0, "gp_patchify_xyz: bad argument");
+    GP_DT_OK(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * R * R;
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 0.0, total * (16.0 + 3 * (dtype == GP_F16 ? 2 : 4)));
+    if (dtype == GP_F16) hipLaunchKernelGGL(patchify_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, (half_t*)out, B, R, P);
+    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, (float*)out, B, R, P);
+    GP_LAUNCH_CHECK("gp_patchify_xyz");
+}
+
+extern "C" int gp_attention64(const void* qkv, void* out, int B, int heads, int dtype, void* stream) {
+    GP_REQUIRE(qkv && out && B > 0 && heads > 0, "gp_attention64: bad argument");
+    GP_DT_OK(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 4.0 * B * heads * 64 * 64 * 32, (double)B * 64 * heads * 32 * 4 * (dtype == GP_F16 ? 2 : 4));
+    if (dtype == GP_F16) hipLaunchKernelGGL(attention64_kernel<half_t>, dim3(B * heads), dim3(64), 0, s, (const half_t*)qkv, (half_t*)out, heads);
+    else hipLaunchKernelGGL(attention64_kernel<float>, dim3(B * heads), dim3(64), 0, s, (const float*)qkv, (float*)out, heads);
+    GP_LAUNCH_CHECK("gp_attention64");
 }
 
 extern "C" int gp_resnet_stem(const float* img, const float* w, const float* b, void* out, int B, int H, int W, int dtype,

@@ -309,7 +309,7 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ y,
-                                                        long rows, int C, float eps) {
+                                                        long rows, int C, float eps, int ldy) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float red[4];
     const int CT = C / VEC, PG = 256 / CT;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o.set(e, a[e] * rstd * gw[e] + gb[e]);
-    store16<T>(y + row * C + cs * VEC, o);
+    store16<T>(y + row * ldy + cs * VEC, o);
 }
 
 // ---------------------------------------------------------------------------- GroupNorm
@@ -512,7 +512,8 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
 }
 
 extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,
-                            int dtype, void* stream) {
+                            int ldy, int dtype, void* stream) {
+    if (ldy <= 0) ldy = C;
     GP_REQUIRE(x && w && b && y && rows > 0, "gp_layernorm: bad argument");
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_layernorm: bad dtype");
     const int esz = dtype == GP_F16 ? 2 : 4;
@@ -521,9 +522,9 @@ extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void*
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 8.0 * rows * C, (double)rows * C * esz * 2);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps);
+        hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps, ldy);
     else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps);
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps, ldy);
     GP_LAUNCH_CHECK("gp_layernorm");
 }
 

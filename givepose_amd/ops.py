@@ -186,11 +186,21 @@ def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels
     return out
 
 
-def layernorm(x, w, b, out, eps=1e-6):
+def layernorm(x, w, b, out, eps=1e-6, ldy=0):
     C = x.shape[-1]
     rows = x.numel() // C
-    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, dtype_code(x.dtype), _stream()),
+    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, ldy, dtype_code(x.dtype), _stream()),
           "gp_layernorm")
+    return out
+
+
+def patchify_xyz(xyz4, out, B, R, P):
+    check(_L().gp_patchify_xyz(_ptr(xyz4), _ptr(out), B, R, P, dtype_code(out.dtype), _stream()), "gp_patchify_xyz")
+    return out
+
+
+def attention64(qkv, out, B, heads):
+    check(_L().gp_attention64(_ptr(_contig(qkv, "qkv")), _ptr(out), B, heads, dtype_code(qkv.dtype), _stream()), "gp_attention64")
     return out
 
 

@@ -143,7 +143,22 @@ class PoseNet(nn.Module):
         W["size.w1"] = f32(sd["size_head.conv1.weight"].squeeze(-1) * sc[:, None])
         W["size.b1"] = f32((sd["size_head.conv1.bias"] - sd["size_head.bn1.running_mean"]) * sc + sd["size_head.bn1.bias"])
         W["size.w2"], W["size.b2"] = f32(sd["size_head.conv2.weight"].squeeze(-1)), f32(sd["size_head.conv2.bias"])
-        for li, i in enumerate((0, 3, 6)):
+        if cfg.nocsmap_encoder == "att":      # MAPTransformerEncoer (network/attention_pnp_net.py:126-157)
+            a = lambda k: sd["nocs_encoder." + k]
+            W["att.pe_w"] = lowp(a("patch_embed.proj.weight").permute(0, 2, 3, 1).reshape(256, -1))   # K = (ky,kx,c)
+            W["att.pe_b"] = f32(a("patch_embed.proj.bias"))
+            W["att.pos"] = a("pos_embed").reshape(64, 256)                                           # tiled per batch in _plan
+            W["att.ones"] = torch.ones(256, dtype=torch.float32, device=device)
+            W["att.norm_w"], W["att.norm_b"] = f32(a("norm.weight")), f32(a("norm.bias"))
+            for i in range(3):
+                q = f"att{i}."
+                for n in ("norm1", "norm2"):
+                    W[q + n + "_w"], W[q + n + "_b"] = f32(a(f"block.{i}.{n}.weight")), f32(a(f"block.{i}.{n}.bias"))
+                W[q + "qkv_w"] = lowp(a(f"block.{i}.attn.qkv.weight"))
+                W[q + "proj_w"], W[q + "proj_b"] = lowp(a(f"block.{i}.attn.proj.weight")), f32(a(f"block.{i}.attn.proj.bias"))
+                W[q + "fc1_w"], W[q + "fc1_b"] = lowp(a(f"block.{i}.mlp.fc1.weight")), f32(a(f"block.{i}.mlp.fc1.bias"))
+                W[q + "fc2_w"], W[q + "fc2_b"] = lowp(a(f"block.{i}.mlp.fc2.weight")), f32(a(f"block.{i}.mlp.fc2.bias"))
+        for li, i in enumerate((0, 3, 6) if cfg.nocsmap_encoder == "conv" else ()):
             p, q = f"nocs_encoder.features.{i}.", f"enc{li}."
             if cfg.use_dcn == "dcnv3":
                 cw = sd[p + "conv.weight"].reshape(256, -1)
@@ -223,6 +238,10 @@ class PoseNet(nn.Module):
             buf[f"e_x1{li}"] = e(B * r * r // 4, 256)
             buf[f"e_om{li}"] = f(B * r * r // 4, 108)
             buf[f"e_g{li}"], buf[f"e_o{li}"] = e(B, r // 2, r // 2, 256), e(B, r // 2, r // 2, 256)
+        if cfg.nocsmap_encoder == "att":
+            buf["a_patch"], buf["a_x"], buf["a_h"] = e(B * 64, 192), e(B * 64, 256), e(B * 64, 256)
+            buf["a_qkv"], buf["a_att"], buf["a_mlp"] = e(B * 64, 768), e(B * 64, 256), e(B * 64, 1024)
+            buf["a_pos"] = self._packed["att.pos"].to(T).repeat(B, 1).contiguous()      # pos_embed per token row
         buf["feat_cat"] = e(B, 8, 8, 512)
         buf["p0"], buf["p1"], buf["p2"] = e(B, 32, 32, 128), e(B, 16, 16, 128), e(B, 8, 8, 128)
         buf["fc1"] = e(B, 2048)
@@ -310,7 +329,23 @@ class PoseNet(nn.Module):
         # ---- MAPEncoder (network/conv_pnp_net.py:303-332)
         cat2d = buf["feat_cat"].view(B * 64, 512)
         prev = None
-        for li, r in enumerate((64, 32, 16)):
+        if cfg.nocsmap_encoder == "att":
+            # ---- MAPTransformerEncoer (network/attention_pnp_net.py:143-157): 64 tokens x 256, 3 pre-norm ViT blocks
+            x = buf["a_x"]
+            ops.patchify_xyz(buf["nocs_nhwc4"], buf["a_patch"], B, cfg.out_res, 8)
+            ops.gemm(buf["a_patch"], W["att.pe_w"], x, bias=W["att.pe_b"], epilogue=EPI_SCALE_RES, gamma=W["att.ones"],
+                     residual=buf["a_pos"])                                   # proj(x) + bias + pos_embed
+            for i in range(3):
+                q = f"att{i}."
+                h = ops.layernorm(x, W[q + "norm1_w"], W[q + "norm1_b"], buf["a_h"], eps=1e-5)
+                ops.gemm(h, W[q + "qkv_w"], buf["a_qkv"])
+                ops.attention64(buf["a_qkv"], buf["a_att"], B, 8)
+                ops.gemm(buf["a_att"], W[q + "proj_w"], x, bias=W[q + "proj_b"], epilogue=EPI_SCALE_RES, gamma=W["att.ones"], residual=x)
+                h = ops.layernorm(x, W[q + "norm2_w"], W[q + "norm2_b"], buf["a_h"], eps=1e-5)
+                ops.gemm(h, W[q + "fc1_w"], buf["a_mlp"], bias=W[q + "fc1_b"], epilogue=EPI_GELU)
+                ops.gemm(buf["a_mlp"], W[q + "fc2_w"], x, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES, gamma=W["att.ones"], residual=x)
+            ops.layernorm(x, W["att.norm_w"], W["att.norm_b"], cat2d[:, 256:], eps=1e-5, ldy=512)   # -> right half of feat_cat
+        for li, r in enumerate((64, 32, 16) if cfg.nocsmap_encoder == "conv" else ()):
             q = f"enc{li}."
             ro = r // 2
             if cfg.use_dcn == "dcnv3":

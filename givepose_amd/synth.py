@@ -112,8 +112,29 @@ def param_manifest(cfg: PoseNetConfig = PoseNetConfig()):
     m["size_head.bn1.running_mean"] = (cfg.feat_ts,)
     m["size_head.bn1.running_var"] = (cfg.feat_ts,)
     m["size_head.bn1.num_batches_tracked"] = ()
-    assert cfg.nocsmap_encoder == "conv"
-    for li, i in enumerate((0, 3, 6)):
+    if cfg.nocsmap_encoder == "att":
+        # MAPTransformerEncoer (network/attention_pnp_net.py:126-157): own Parameter first, then children in
+        # registration order (norm, patch_embed, block); timm 0.9.6 Block(dim=256, num_heads=8): qkv without bias
+        p = "nocs_encoder."
+        m[p + "pos_embed"] = (1, 64, 256)
+        m[p + "norm.weight"] = (256,)
+        m[p + "norm.bias"] = (256,)
+        m[p + "patch_embed.proj.weight"] = (256, 3, 8, 8)
+        m[p + "patch_embed.proj.bias"] = (256,)
+        for i in range(3):
+            q = f"{p}block.{i}."
+            m[q + "norm1.weight"] = (256,)
+            m[q + "norm1.bias"] = (256,)
+            m[q + "attn.qkv.weight"] = (768, 256)
+            m[q + "attn.proj.weight"] = (256, 256)
+            m[q + "attn.proj.bias"] = (256,)
+            m[q + "norm2.weight"] = (256,)
+            m[q + "norm2.bias"] = (256,)
+            m[q + "mlp.fc1.weight"] = (1024, 256)
+            m[q + "mlp.fc1.bias"] = (1024,)
+            m[q + "mlp.fc2.weight"] = (256, 1024)
+            m[q + "mlp.fc2.bias"] = (256,)
+    for li, i in enumerate((0, 3, 6) if cfg.nocsmap_encoder == "conv" else ()):
         cin = 3 if li == 0 else 256
         p = f"nocs_encoder.features.{i}"
         if cfg.use_dcn == "dcnv3":

@@ -115,8 +115,8 @@ int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* 
                  void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
                  void* stream);
 
-/* row LayerNorm over C (ConvNeXt downsample LayerNorm2d). */
-int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,
+/* row LayerNorm over C (ConvNeXt downsample LayerNorm2d, ViT-block norms); y row stride ldy (0 = C). */
+int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps, int ldy,
                  int dtype, void* stream);
 
 /* GroupNorm (nn.GroupNorm(G, C), eps) over channels-last x (B, HW, C):
@@ -174,6 +174,13 @@ int gp_pose_tail(const float* h, const float* hz, int ldh, const float* w_r, con
                  const float* bbox_center, const float* resize_ratio, const float* roi_wh, int wild6d,
                  int site_centroid, float* rot6d, float* pred_t, float* rot_allo, float* rot_ego,
                  float* trans, int B, void* stream);
+
+/* MAPTransformerEncoer front end (network/attention_pnp_net.py:126-157, PatchEmbed :264-302): gather the PxP patches
+ * of the (B*R*R,4) fp32 coordinate map into GEMM rows (B*(R/P)^2, P*P*3) of `dtype`, k = (ky*P+kx)*3 + c. */
+int gp_patchify_xyz(const float* xyz4, void* out, int B, int R, int P, int dtype, void* stream);
+/* Multi-head self-attention core of timm 0.9.6 vision_transformer.Attention for 64 tokens x head_dim 32: qkv rows
+ * (B*64, 3*heads*32) laid out [q|k|v][head][32]; out (B*64, heads*32) = softmax(q k^T / sqrt(32)) v, fp32 math. */
+int gp_attention64(const void* qkv, void* out, int B, int heads, int dtype, void* stream);
 
 /* ResNet stem (network/resnet.py:137-141): Conv2d(3,64,7,s2,p3,bias=False) + eval BatchNorm (folded by the host into
  * w / b) + ReLU on the NCHW fp32 image -> (B,H/2,W/2,64) channels-last.  w: (147, 64) fp32 tap-major, k = c*49+kh*7+kw. */

@@ -165,6 +165,29 @@ def dcnv3_module_ref(P, x_nhwc, prefix, stride=2, G=4, K=3, pad=1, dil=1, offset
     return F.linear(y, g("output_proj.weight"), g("output_proj.bias"))
 
 
+def map_transformer_ref(P, coor, prefix="nocs_encoder."):
+    """network/attention_pnp_net.py:143-157 (MAPTransformerEncoer.forward), PatchEmbed :297-302, and timm 0.9.6
+    vision_transformer.Block / Attention / Mlp [third-party, from memory -- UNPINNED against timm]: pre-norm MHA
+    (8 heads x 32, qkv without bias, scale 32**-0.5) + MLP (x4, exact GELU), LayerNorm eps 1e-5.  (B,3,64,64)->(B,256,8,8)."""
+    g = lambda k: P[prefix + k]
+    x = F.conv2d(coor, g("patch_embed.proj.weight"), g("patch_embed.proj.bias"), stride=8).flatten(2).transpose(1, 2)
+    x = x + g("pos_embed")
+    B, N, C = x.shape
+    for i in range(3):
+        q = f"block.{i}."
+        h = F.layer_norm(x, (C,), g(q + "norm1.weight"), g(q + "norm1.bias"), 1e-5)
+        qkv = F.linear(h, g(q + "attn.qkv.weight")).reshape(B, N, 3, 8, C // 8).permute(2, 0, 3, 1, 4)
+        qq, kk, vv = qkv.unbind(0)
+        att = ((qq * (C // 8) ** -0.5) @ kk.transpose(-2, -1)).softmax(dim=-1)
+        h = (att @ vv).transpose(1, 2).reshape(B, N, C)
+        x = x + F.linear(h, g(q + "attn.proj.weight"), g(q + "attn.proj.bias"))
+        h = F.layer_norm(x, (C,), g(q + "norm2.weight"), g(q + "norm2.bias"), 1e-5)
+        h = F.linear(F.gelu(F.linear(h, g(q + "mlp.fc1.weight"), g(q + "mlp.fc1.bias"))), g(q + "mlp.fc2.weight"), g(q + "mlp.fc2.bias"))
+        x = x + h
+    x = F.layer_norm(x, (C,), g("norm.weight"), g("norm.bias"), 1e-5)
+    return x.permute(0, 2, 1).reshape(B, C, 8, 8)
+
+
 def map_encoder_ref(P, coor, cfg, prefix="nocs_encoder."):
     """network/conv_pnp_net.py:303-332 (MAPEncoder.forward) with layers :254-272:
     3 x [DCNv3_C(s2) | Conv3x3 s2 (use_dcn='')] -> GN(32) -> ReLU.  DCNv3_C: network/dcnv3.py:32-38."""
@@ -259,7 +282,7 @@ def posenet_forward_ref(P, data, cfg, return_intermediates=False):
     feat = convnext_ref(P, img, cfg) if cfg.main_backbone == "convnext" else resnet34_ref(P, img)
     pred_size = size_head_ref(P, feat[0])
     nocs = xyz_head_ref(P, feat[0], "xyz_nocs_head.")
-    nocs_feat = map_encoder_ref(P, nocs, cfg)
+    nocs_feat = map_transformer_ref(P, nocs) if cfg.nocsmap_encoder == "att" else map_encoder_ref(P, nocs, cfg)
     red = F.conv2d(feat[0], P["feat_reducer.weight"], P["feat_reducer.bias"])
     ivfc = xyz_head_ref(P, torch.cat([red, nocs_feat], dim=1), "xyz_deform_head.")
     rot6d, pred_t = conv_pnp_ref(P, torch.cat([ivfc, f("roi_coord_2d")], dim=1))

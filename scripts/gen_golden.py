@@ -243,6 +243,24 @@ def gen_e2e():
              **{"mid_" + k: v for k, v in inter.items()})
 
 
+def gen_att():
+    """network/attention_pnp_net.py MAPTransformerEncoer (nocsmap_encoder='att'); timm Block = ref_shim restatement."""
+    from network.attention_pnp_net import MAPTransformerEncoer
+    print("MAPTransformerEncoer")
+    cfg = PoseNetConfig(nocsmap_encoder="att")
+    m = load_synth_into(MAPTransformerEncoer().eval(), "nocs_encoder.")
+    ours = [k for k in synth.param_manifest(cfg) if k.startswith("nocs_encoder.")]
+    assert ours == ["nocs_encoder." + k for k in m.state_dict()], "att manifest order/name mismatch"
+    r = np.random.Generator(np.random.Philox(key=[SEED, 13]))
+    x = torch.from_numpy(r.uniform(-0.6, 0.6, (3, 3, 64, 64)).astype(np.float32))
+    exp = m(x)
+    Pn = O.load_params(synth.synth_state_dict(cfg, SEED))
+    d = maxdiff(exp, O.map_transformer_ref(Pn, x))
+    print(f"  oracle vs reference {d:.2e} |out| {float(exp.abs().mean()):.3f}")
+    assert d < 2e-5
+    save("map_transformer", x=x, expected=exp)
+
+
 def gen_resnet():
     """network/resnet.py resnet34 trunk (conv1..layer4 in the order of ResNet.forward :137-147; avgpool/fc dropped:
     SURVEY.md 8a row a14).  The class is pure torch, so it is the reference's own arithmetic."""
@@ -263,9 +281,11 @@ def gen_resnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["core", "modules", "e2e", "resnet"]
+    which = sys.argv[1:] or ["core", "modules", "e2e", "resnet", "att"]
     if "resnet" in which:
         gen_resnet()
+    if "att" in which:
+        gen_att()
     if "core" in which:
         gen_dcnv3_core()
     if "modules" in which:

@@ -134,3 +134,22 @@ def test_resnet34_variant_matches_oracle(dtype, tol):
     err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print("resnet34", dtype, err)
     assert all(v < tol for v in err.values()), err
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float16, 5e-2)])
+def test_attention_encoder_variant_matches_oracle(dtype, tol):
+    """a13 / BASELINE config 4's in-repo analogue: nocsmap_encoder='att' (MAPTransformerEncoer, 64 tokens, 3 ViT blocks)."""
+    from givepose_amd import synth
+    from givepose_amd.config import PoseNetConfig
+    from oracle import posenet_ref as O
+    cfg = PoseNetConfig(nocsmap_encoder="att")
+    net = _model(dtype, nocsmap_encoder="att")
+    data = _batch(3, 19)
+    ref = O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg, return_intermediates=True)
+    dev = net.forward_device(data)
+    nf = dev["feat_cat"][..., 256:].float().cpu().permute(0, 3, 1, 2)
+    print("nocs_feat err", float((nf - ref["nocs_feat"]).abs().max()))
+    out = net(data, "cuda")
+    err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    print("att", dtype, err)
+    assert all(v < tol for v in err.values()), err

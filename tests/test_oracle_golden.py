@@ -107,3 +107,10 @@ def test_resnet34_trunk(golden):
     P = O.load_params(synth.synth_state_dict(PoseNetConfig(main_backbone="resnet34"), 0))
     got = O.resnet34_ref(P, T(z["x"]))[0].numpy()
     assert np.abs(got - z["expected"]).max() < 1e-4
+
+
+def test_map_transformer(golden):
+    """a13: oracle MAPTransformerEncoer vs the reference class (timm Block restated from memory in ref_shim: unpinned vs timm)."""
+    z = golden("map_transformer")
+    P = O.load_params(synth.synth_state_dict(PoseNetConfig(nocsmap_encoder="att"), 0))
+    assert np.abs(O.map_transformer_ref(P, T(z["x"])).numpy() - z["expected"]).max() < 2e-5
