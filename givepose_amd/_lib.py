@@ -41,6 +41,7 @@ PROTOTYPES = {
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),
     "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 4 + [_P], c_int),
+    "gp_groupnorm_apply_xyz": ([_P] * 8 + [c_int] * 4 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_upsample_bilinear2x": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_deconv_col2im": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_xyz_out_layer": ([_P] * 5 + [c_int] * 4 + [_P], c_int),

@@ -459,6 +459,90 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// GroupNorm apply + activation + the head's 1x1 out layer (C -> 3) in one pass: the normalised 64x64x256 tensor is
+// consumed only by that out layer (network/xyz_head.py:352-357), so it is never written -- saves a 134 MB write
+// and a 134 MB read per head at bs = 64.  out_nchw (B,3,HW) fp32 + out_nhwc4 (B*HW,4) fp32, as gp_xyz_out_layer.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__ x, const float* __restrict__ partial,
+                                                           const float* __restrict__ w, const float* __restrict__ bb,
+                                                           const float* __restrict__ ow, const float* __restrict__ ob,
+                                                           float* __restrict__ out_nchw, float* __restrict__ out_nhwc4,
+                                                           int HW, int C, int G, int act, int chunks, float inv_count,
+                                                           float eps, int GN_PXB) {
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float st[256][2];
+    __shared__ float red[4 * 3];
+    const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
+    const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
+    const int b = blockIdx.y;
+    if (threadIdx.x < G) {
+        double a = 0.0, q = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            const float* p = partial + (((long)b * chunks + c) * G + threadIdx.x) * 2;
+            a += p[0];
+            q += p[1];
+        }
+        const double mean = a * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[threadIdx.x][0] = (float)mean;
+        st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
+    float sc[VEC], sh[VEC], w0[VEC], w1[VEC], w2[VEC];
+    {
+        float gw[VEC], gb[VEC];
+        load_f32<T>(w + cs * VEC, gw);
+        load_f32<T>(bb + cs * VEC, gb);
+        load_f32<T>(ow + cs * VEC, w0);
+        load_f32<T>(ow + C + cs * VEC, w1);
+        load_f32<T>(ow + 2 * C + cs * VEC, w2);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int g = (cs * VEC + e) / cpg;
+            sc[e] = st[g][1] * gw[e];
+            sh[e] = gb[e] - st[g][0] * sc[e];
+        }
+    }
+    const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
+    const T* xb = x + ((long)b * HW) * C + cs * VEC;
+    const int iters = (GN_PXB + PG - 1) / PG;   // uniform trip count: the reduction below needs every thread
+    for (int it = 0; it < iters; ++it) {
+        const int p = p0 + pl + it * PG;
+        float d[3] = {0.f, 0.f, 0.f};
+        if (p < p1) {
+            const Vec16<T> v = load16<T>(xb + (long)p * C);
+            float a[VEC];
+            if (act == GP_ACT_GELU && sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < VEC; e += 2) {
+                    const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
+                    a[e] = g[0];
+                    a[e + 1] = g[1];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) a[e] = apply_act(v.get(e) * sc[e] + sh[e], act);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                d[0] = fmaf(a[e], w0[e], d[0]);
+                d[1] = fmaf(a[e], w1[e], d[1]);
+                d[2] = fmaf(a[e], w2[e], d[2]);
+            }
+        }
+        pixel_group_sum<3>(d, CT, red);
+        if (p < p1 && cs == 0) {
+            const long row = (long)b * HW + p;
+            out_nchw[((long)b * 3 + 0) * HW + p] = d[0] + b0;
+            out_nchw[((long)b * 3 + 1) * HW + p] = d[1] + b1;
+            out_nchw[((long)b * 3 + 2) * HW + p] = d[2] + b2;
+            *reinterpret_cast<f32x4*>(out_nhwc4 + row * 4) = f32x4{d[0] + b0, d[1] + b1, d[2] + b2, 0.f};
+        }
+    }
+}
+
 bool ct_ok(int C, int esz) {
     const int vec = 16 / esz;
     if (C % vec) return false;
@@ -567,4 +651,23 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     else
         hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
     GP_LAUNCH_CHECK("gp_groupnorm_apply");
+}
+
+extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const float* w, const float* b,
+                                      const float* out_w, const float* out_b, float* out_nchw, float* out_nhwc4, int B,
+                                      int HW, int C, int G, float eps, int act, int chunks_in, int dtype, void* stream) {
+    GP_REQUIRE(x && partial && w && b && out_w && out_b && out_nchw && out_nhwc4 && B > 0 && HW > 0, "gp_groupnorm_apply_xyz: bad argument");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply_xyz: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4;
+    GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_apply_xyz: unsupported C=%d G=%d", C, G);
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_NORM, 10.0 * B * HW * C, (double)B * HW * (C * esz + 28));
+    const int pxb = gn_pxb(B, HW), chunks = chunks_in > 0 ? chunks_in : cdiv(HW, pxb);
+    const float inv_count = 1.0f / ((float)HW * (C / G));
+    dim3 grid(cdiv(HW, pxb), B);
+    if (dtype == GP_F16)
+        hipLaunchKernelGGL(gn_apply_xyz_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, C, G, act, chunks, inv_count, eps, pxb);
+    else
+        hipLaunchKernelGGL(gn_apply_xyz_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, C, G, act, chunks, inv_count, eps, pxb);
+    GP_LAUNCH_CHECK("gp_groupnorm_apply_xyz");
 }

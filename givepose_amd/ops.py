@@ -220,6 +220,14 @@ def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=Fal
     return out
 
 
+def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5):
+    """GroupNorm apply (statistics already in ``partial`` in 64-row chunks) + act + 1x1 out layer, nothing else written."""
+    B, HW, C = x.shape
+    check(_L().gp_groupnorm_apply_xyz(_ptr(_contig(x, "x")), _ptr(partial), _ptr(w), _ptr(b), _ptr(out_w), _ptr(out_b),
+                                      _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C, G, eps, act, HW // 64, dtype_code(x.dtype),
+                                      _stream()), "gp_groupnorm_apply_xyz")
+
+
 def upsample_bilinear2x(x, out):
     B, H, W_, C = x.shape
     check(_L().gp_upsample_bilinear2x(_ptr(_contig(x, "x")), _ptr(out), B, H, W_, C, dtype_code(x.dtype), _stream()),

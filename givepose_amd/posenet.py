@@ -171,6 +171,11 @@ class PoseNet(nn.Module):
                 W[q + "om_w"] = lowp(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
                 W[q + "om_b"] = f32(torch.cat([sd[d + "offset.bias"], sd[d + "mask.bias"]], 0))
                 W[q + "in_w"], W[q + "in_b"] = lowp(sd[d + "input_proj.weight"]), f32(sd[d + "input_proj.bias"])
+                # input_proj(conv1x1(x)) is one linear map: fold the two (fp32 product, then storage rounding) so the
+                # full-resolution 256-channel `conv` output is only materialised for the prefix the dw_conv branch reads
+                wf = sd[d + "input_proj.weight"] @ cw
+                W[q + "fold_w"] = f32(wf) if li == 0 else lowp(wf)
+                W[q + "fold_b"] = f32(sd[d + "input_proj.weight"] @ sd[p + "conv.bias"] + sd[d + "input_proj.bias"])
                 W[q + "out_w"], W[q + "out_b"] = lowp(sd[d + "output_proj.weight"]), f32(sd[d + "output_proj.bias"])
             else:
                 cw = sd[p + "weight"]
@@ -275,9 +280,12 @@ class PoseNet(nn.Module):
                 cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"])
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
             ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r))
-            self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True)
+            if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
+                ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
+                                        W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"])
+            else:
+                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True)
             cur = dst
-        ops.xyz_out_layer(cur.view(B, r * r, 256), W[head + ".out_w"], W[head + ".out_b"], out_nchw, out_nhwc4)
 
     def _resnet34(self, W, buf):
         """network/resnet.py:137-147 (ResNet.forward up to layer4), BasicBlock :38-52; eval BatchNorm folded into the
@@ -350,12 +358,14 @@ class PoseNet(nn.Module):
             ro = r // 2
             if cfg.use_dcn == "dcnv3":
                 xin = buf[f"e_in{li}"]
-                if li == 0:
-                    ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "conv_w"], W[q + "conv_b"], xin.view(-1, 256))
-                else:
-                    ops.gemm(prev.view(-1, 256), W[q + "conv_w"], xin.view(-1, 256), bias=W[q + "conv_b"])
-                ops.gemm(xin.view(-1, 256), W[q + "in_w"], buf[f"e_proj{li}"].view(-1, 256), bias=W[q + "in_b"])
                 nq = B * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
+                npre = min(B * r * r, nq + r + 8)   # + one image row of halo for the 3x3 depth-wise conv
+                if li == 0:
+                    ops.pointwise_k3(buf["nocs_nhwc4"][:npre], W[q + "conv_w"], W[q + "conv_b"], xin.view(-1, 256)[:npre])
+                    ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "fold_w"], W[q + "fold_b"], buf[f"e_proj{li}"].view(-1, 256))
+                else:
+                    ops.gemm(prev.view(-1, 256)[:npre], W[q + "conv_w"], xin.view(-1, 256)[:npre], bias=W[q + "conv_b"])
+                    ops.gemm(prev.view(-1, 256), W[q + "fold_w"], buf[f"e_proj{li}"].view(-1, 256), bias=W[q + "fold_b"])
                 ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"e_x1{li}"], 3,
                               act=ACT_GELU, n_pixels=nq)
                 om = ops.gemm(buf[f"e_x1{li}"], W[q + "om_w"], buf[f"e_om{li}"], bias=W[q + "om_b"])

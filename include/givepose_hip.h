@@ -130,6 +130,12 @@ int gp_groupnorm_apply(const void* x, const float* partial, const float* w, cons
                        int HW, int C, int G, float eps, int act, int ldy, int chunks /* 0 = gp_groupnorm_chunks */,
                        int dtype, void* stream);
 
+/* gp_groupnorm_apply fused with gp_xyz_out_layer (the normalised tensor is consumed only by the 1x1 out layer and is
+ * never written): out_w (3,C), out_b (3) fp32; outputs as gp_xyz_out_layer. */
+int gp_groupnorm_apply_xyz(const void* x, const float* partial, const float* w, const float* b, const float* out_w,
+                           const float* out_b, float* out_nchw, float* out_nhwc4, int B, int HW, int C, int G,
+                           float eps, int act, int chunks, int dtype, void* stream);
+
 /* nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), channels-last (xyz_head.py:264). */
 int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
