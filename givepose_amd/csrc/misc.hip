@@ -40,16 +40,15 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     const int ppw = PXB / 4;
     for (int q = 0; q < ppw; ++q) {
         const int p = wave * ppw + q;
-        float a0 = bv.x, a1 = bv.y;
+        f32x2 a01 = {bv.x, bv.y};     // both channels of the lane in one v_pk_fma_f32 per tap
 #pragma unroll
         for (int row = 0; row < 12; ++row) {
             const f32x4 iv = *reinterpret_cast<const f32x4*>(&in_s[row][p * 4]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a0 = fmaf(iv[j], wr[row * 4 + j].x, a0);
-                a1 = fmaf(iv[j], wr[row * 4 + j].y, a1);
-            }
+            for (int j = 0; j < 4; ++j)
+                a01 = __builtin_elementwise_fma(f32x2{iv[j], iv[j]}, f32x2{wr[row * 4 + j].x, wr[row * 4 + j].y}, a01);
         }
+        float a0 = a01[0], a1 = a01[1];
         const float mean = group_sum(a0 + a1, 64) * (1.0f / C0);
         a0 -= mean;
         a1 -= mean;
@@ -180,51 +179,63 @@ __global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------- tiny-Cin 3x3 s2 conv
 // input channels: c < 3 from xyz4 (B*R*R, 4); c in {3,4} from coord2d (B,2,R,R) when CIN == 5.
-// wt: (CIN*9, Cout) fp32, k = ci*9 + kh*3 + kw.  Block = 64 output pixels, filter bank staged once in LDS.
+// wt: (CIN*9, Cout) fp32, k = ci*9 + kh*3 + kw.  Filter bank staged once in LDS; a thread owns 4 output channels of
+// 4 consecutive output pixels of a row, so every 16-B filter read from LDS feeds 16 FMAs.
 template <typename T, int CIN>
 __global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __restrict__ xyz4,
                                                                 const float* __restrict__ coord2d,
                                                                 const float* __restrict__ wt, T* __restrict__ y,
                                                                 int B, int R, int Cout) {
-    constexpr int KK = CIN * 9, PIXB = 64;
+    constexpr int KK = CIN * 9, PPT = 4;
     extern __shared__ __attribute__((aligned(16))) float w_s[];  // [KK][Cout]
     for (int i = threadIdx.x; i < KK * Cout; i += 256) w_s[i] = wt[i];
     __syncthreads();
-    const int Ro = R / 2, CQ = Cout / 4, PB = 256 / CQ;
+    const int Ro = R / 2, CQ = Cout / 4, PB = 256 / CQ;          // PB pixel-quads per block
     const int cq = threadIdx.x % CQ;
-    const long npix = (long)B * Ro * Ro;
-    for (int it = threadIdx.x / CQ; it < PIXB; it += PB) {
-        const long pix = (long)blockIdx.x * PIXB + it;
-        if (pix >= npix) break;
-        const int wo = (int)(pix % Ro);
-        const long t = pix / Ro;
-        const int ho = (int)(t % Ro);
-        const long b = t / Ro;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hi = ho * 2 - 1 + kh;
-            if ((unsigned)hi >= (unsigned)R) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int wi = wo * 2 - 1 + kw;
-                if ((unsigned)wi >= (unsigned)R) continue;
-                const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + hi) * R + wi) * 4);
-                float in[CIN];
-                in[0] = p[0]; in[1] = p[1]; in[2] = p[2];
-                if constexpr (CIN == 5) {
-                    in[3] = coord2d[((b * 2 + 0) * R + hi) * R + wi];
-                    in[4] = coord2d[((b * 2 + 1) * R + hi) * R + wi];
-                }
+    const long nquad = (long)B * Ro * (Ro / PPT);
+    const long quad = (long)blockIdx.x * PB + threadIdx.x / CQ;
+    if (quad >= nquad) return;
+    const int wq = (int)(quad % (Ro / PPT));
+    const long t = quad / (Ro / PPT);
+    const int ho = (int)(t % Ro);
+    const long b = t / Ro;
+    const int wo0 = wq * PPT;
+    float acc[PPT][4];
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + (c * 9 + kh * 3 + kw) * Cout + cq * 4);
+    for (int p = 0; p < PPT; ++p)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += in[c] * wv[e];
-                }
+        for (int e = 0; e < 4; ++e) acc[p][e] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if ((unsigned)hi >= (unsigned)R) continue;
+        float in[2 * PPT + 1][CIN];                                // input columns wo0*2-1 .. wo0*2+2*PPT-1
+#pragma unroll
+        for (int c = 0; c < 2 * PPT + 1; ++c) {
+            const int wi = wo0 * 2 - 1 + c;
+            const bool ok = (unsigned)wi < (unsigned)R;
+            const f32x4 p4 = ok ? *reinterpret_cast<const f32x4*>(xyz4 + ((b * R + hi) * R + wi) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            in[c][0] = p4[0]; in[c][1] = p4[1]; in[c][2] = p4[2];
+            if constexpr (CIN == 5) {
+                in[c][3] = ok ? coord2d[((b * 2 + 0) * R + hi) * R + wi] : 0.f;
+                in[c][4] = ok ? coord2d[((b * 2 + 1) * R + hi) * R + wi] : 0.f;
             }
         }
-        T* o = y + pix * Cout + cq * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store_T(o + e, acc[e]);
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w_s + (c * 9 + kh * 3 + kw) * Cout + cq * 4);
+#pragma unroll
+                for (int p = 0; p < PPT; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[p][e] = fmaf(in[2 * p + kw][c], wv[e], acc[p][e]);
+            }
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        T* o = y + ((b * Ro + ho) * Ro + wo0 + p) * Cout + cq * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) store_T(o + e, acc[p][e]);
     }
 }
 
@@ -575,7 +586,7 @@ extern "C" int gp_pointwise_k3(const float* xyz4, const float* w, const float* b
 template <int CIN>
 static int launch_smallcin(const float* xyz4, const float* coord2d, const float* w, void* y, int B, int R, int Cout,
                            int dtype, void* stream, const char* name) {
-    GP_REQUIRE(xyz4 && w && y && B > 0 && R % 2 == 0, "%s: bad argument", name);
+    GP_REQUIRE(xyz4 && w && y && B > 0 && R % 8 == 0, "%s: bad argument", name);
     GP_DT_OK(dtype);
     GP_REQUIRE(Cout % 4 == 0 && Cout / 4 <= 256 && 256 % (Cout / 4) == 0, "%s: Cout=%d", name, Cout);
     hipStream_t s = (hipStream_t)stream;
@@ -583,9 +594,9 @@ static int launch_smallcin(const float* xyz4, const float* coord2d, const float*
         const size_t lds = (size_t)CIN * 9 * Cout * sizeof(float);
     gp_timing_before(s, GP_KC_SMALL, 2.0 * pix * CIN * 9 * Cout, (double)B * R * R * CIN * 4 + (double)pix * Cout * (dtype == GP_F16 ? 2 : 4));
     if (dtype == GP_F16)
-        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix, 64)), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix / 4, 256 / (Cout / 4))), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
     else
-        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix, 64)), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
+        hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix / 4, 256 / (Cout / 4))), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
     GP_LAUNCH_CHECK(name);
 }
 
