@@ -118,13 +118,28 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-// sum over the `width` (power of two, <= 64) consecutive lanes that contain this lane
+// Butterfly reductions over the `width` (power of two, <= 64) consecutive lanes that contain this lane.  Inside a
+// row of 16 lanes the exchange is a DPP operand modifier of a VALU op (quad_perm xor 1 / xor 2, row_half_mirror,
+// row_mirror: after the two quad steps every lane holds its quad's total, so mirroring adds the partner quad / octet);
+// only the 16- and 32-lane steps go through the LDS crossbar (ds_bpermute via __shfl_xor).
+#define GP_DPP_STEP(op, ctrl) v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false)))
+__device__ __forceinline__ float gp_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (width >= 2) GP_DPP_STEP(gp_addf, 0xB1);    // quad_perm [1,0,3,2]
+    if (width >= 4) GP_DPP_STEP(gp_addf, 0x4E);    // quad_perm [2,3,0,1]
+    if (width >= 8) GP_DPP_STEP(gp_addf, 0x141);   // row_half_mirror
+    if (width >= 16) GP_DPP_STEP(gp_addf, 0x140);  // row_mirror
+    if (width >= 32) v += __shfl_xor(v, 16, 64);
+    if (width >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float group_max(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (width >= 2) GP_DPP_STEP(fmaxf, 0xB1);
+    if (width >= 4) GP_DPP_STEP(fmaxf, 0x4E);
+    if (width >= 8) GP_DPP_STEP(fmaxf, 0x141);
+    if (width >= 16) GP_DPP_STEP(fmaxf, 0x140);
+    if (width >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (width >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

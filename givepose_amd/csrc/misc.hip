@@ -157,24 +157,31 @@ __global__ __launch_bounds__(256) void xyz_out_kernel(const T* __restrict__ x, c
     }
 }
 
+// thread = one 16-B vector of output channels (its 3 x VEC weights + bias live in registers) x PXT pixels
 template <typename T>
 __global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restrict__ xyz4, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ y,
                                                            long rows, int Cout) {
-    constexpr int VEC = Vec16<T>::N;
-    const int CT = Cout / VEC;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * CT) return;
-    const int cs = (int)(idx % CT);
-    const long row = idx / CT;
-    const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + row * 4);
-    Vec16<T> o;
+    constexpr int VEC = Vec16<T>::N, PXT = 8;
+    const int CT = Cout / VEC, PG = 256 / CT;
+    const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
+    float w0[VEC], w1[VEC], w2[VEC], bv[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const int n = cs * VEC + e;
-        o.set(e, w[n * 3] * p[0] + w[n * 3 + 1] * p[1] + w[n * 3 + 2] * p[2] + bias[n]);
+        w0[e] = w[n * 3]; w1[e] = w[n * 3 + 1]; w2[e] = w[n * 3 + 2]; bv[e] = bias[n];
     }
-    store16<T>(y + row * Cout + cs * VEC, o);
+    const long r0 = (long)blockIdx.x * PG * PXT + pl;
+#pragma unroll
+    for (int i = 0; i < PXT; ++i) {
+        const long row = r0 + (long)i * PG;
+        if (row >= rows) break;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + row * 4);
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.set(e, fmaf(w0[e], p[0], fmaf(w1[e], p[1], fmaf(w2[e], p[2], bv[e]))));
+        store16<T>(y + row * Cout + cs * VEC, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------- tiny-Cin 3x3 s2 conv
@@ -574,9 +581,9 @@ extern "C" int gp_pointwise_k3(const float* xyz4, const float* w, const float* b
     GP_REQUIRE(xyz4 && w && b && y && rows > 0, "gp_pointwise_k3: bad argument");
     GP_DT_OK(dtype);
     const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
-    GP_REQUIRE(Cout % vec == 0, "gp_pointwise_k3: Cout=%d", Cout);
+    GP_REQUIRE(Cout % vec == 0 && 256 % (Cout / vec) == 0, "gp_pointwise_k3: Cout=%d", Cout);
     hipStream_t s = (hipStream_t)stream;
-    const long total = rows * (Cout / vec);
+    const long total = cdiv(rows, (256 / (Cout / vec)) * 8) * 256;
     gp_timing_before(s, GP_KC_ELEMENTWISE, 6.0 * rows * Cout, rows * 16.0 + (double)rows * Cout * esz);
     if (dtype == GP_F16) hipLaunchKernelGGL(pointwise_k3_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (half_t*)y, rows, Cout);
     else hipLaunchKernelGGL(pointwise_k3_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (float*)y, rows, Cout);

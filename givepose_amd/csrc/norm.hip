@@ -441,21 +441,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
     T* yb = y + ((long)b * HW) * ldy + cs * VEC;
-    for (int p = p0 + pl; p < p1; p += PG) {
-        const Vec16<T> v = load16<T>(xb + (long)p * C);
-        Vec16<T> o;
-        if (act == GP_ACT_GELU && sizeof(T) == 2) {
+    // 4 pixels in flight per thread: the loop is otherwise one dependent HBM round trip per pixel
+    for (int pb = p0 + pl; pb < p1; pb += 4 * PG) {
+        Vec16<T> v[4];
 #pragma unroll
-            for (int e = 0; e < VEC; e += 2) {
-                const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
-                o.set(e, g[0]);
-                o.set(e + 1, g[1]);
+        for (int u = 0; u < 4; ++u)
+            if (pb + u * PG < p1) v[u] = load16<T>(xb + (long)(pb + u * PG) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pb + u * PG;
+            if (p >= p1) break;
+            Vec16<T> o;
+            if (act == GP_ACT_GELU && sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < VEC; e += 2) {
+                    const f32x2 g = gelu_poly2(f32x2{v[u].get(e) * sc[e] + sh[e], v[u].get(e + 1) * sc[e + 1] + sh[e + 1]});
+                    o.set(e, g[0]);
+                    o.set(e + 1, g[1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v[u].get(e) * sc[e] + sh[e], act));
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v.get(e) * sc[e] + sh[e], act));
+            store16<T>(yb + (long)p * ldy, o);
         }
-        store16<T>(yb + (long)p * ldy, o);
     }
 }
 
@@ -508,37 +517,47 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
     const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
     const int iters = (GN_PXB + PG - 1) / PG;   // uniform trip count: the reduction below needs every thread
-    for (int it = 0; it < iters; ++it) {
-        const int p = p0 + pl + it * PG;
-        float d[3] = {0.f, 0.f, 0.f};
-        if (p < p1) {
-            const Vec16<T> v = load16<T>(xb + (long)p * C);
-            float a[VEC];
-            if (act == GP_ACT_GELU && sizeof(T) == 2) {
+    for (int it0 = 0; it0 < iters; it0 += 4) {          // 4 pixels in flight per thread, statically indexed
+        Vec16<T> vq[4];
 #pragma unroll
-                for (int e = 0; e < VEC; e += 2) {
-                    const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
-                    a[e] = g[0];
-                    a[e + 1] = g[1];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) a[e] = apply_act(v.get(e) * sc[e] + sh[e], act);
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                d[0] = fmaf(a[e], w0[e], d[0]);
-                d[1] = fmaf(a[e], w1[e], d[1]);
-                d[2] = fmaf(a[e], w2[e], d[2]);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + pl + (it0 + u) * PG;
+            if (it0 + u < iters && p < p1) vq[u] = load16<T>(xb + (long)p * C);
         }
-        pixel_group_sum<3>(d, CT, red);
-        if (p < p1 && cs == 0) {
-            const long row = (long)b * HW + p;
-            out_nchw[((long)b * 3 + 0) * HW + p] = d[0] + b0;
-            out_nchw[((long)b * 3 + 1) * HW + p] = d[1] + b1;
-            out_nchw[((long)b * 3 + 2) * HW + p] = d[2] + b2;
-            *reinterpret_cast<f32x4*>(out_nhwc4 + row * 4) = f32x4{d[0] + b0, d[1] + b1, d[2] + b2, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (it0 + u >= iters) break;                  // uniform
+            const int p = p0 + pl + (it0 + u) * PG;
+            float d[3] = {0.f, 0.f, 0.f};
+            if (p < p1) {
+                const Vec16<T> v = vq[u];
+                float a[VEC];
+                if (act == GP_ACT_GELU && sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 2) {
+                        const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
+                        a[e] = g[0];
+                        a[e + 1] = g[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) a[e] = apply_act(v.get(e) * sc[e] + sh[e], act);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    d[0] = fmaf(a[e], w0[e], d[0]);
+                    d[1] = fmaf(a[e], w1[e], d[1]);
+                    d[2] = fmaf(a[e], w2[e], d[2]);
+                }
+            }
+            pixel_group_sum<3>(d, CT, red);
+            if (p < p1 && cs == 0) {
+                const long row = (long)b * HW + p;
+                out_nchw[((long)b * 3 + 0) * HW + p] = d[0] + b0;
+                out_nchw[((long)b * 3 + 1) * HW + p] = d[1] + b1;
+                out_nchw[((long)b * 3 + 2) * HW + p] = d[2] + b2;
+                *reinterpret_cast<f32x4*>(out_nhwc4 + row * 4) = f32x4{d[0] + b0, d[1] + b1, d[2] + b2, 0.f};
+            }
         }
     }
 }
