@@ -305,6 +305,238 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
                        (const T*)wt, bias, lnw, lnb, (T*)y, H, W, C, eps, dbg);
 }
 
+// ---------------------------------------------------------------------------- dw7x7 + LN on the matrix cores (fp16)
+// The tiled kernel above is VALU bound (49 taps x 8 channels of v_fma_mix per pixel-thread).  A depthwise filter is
+// a block-diagonal matrix product: for a group of 16 channels and two taps (kh, kw), (kh+1, kw)
+//     D[n][m] += sum_{k=(tap j, channel c)} A[n][k] * B[k][m],  A[n][(j, c)] = (c == n) ? w[tap j][n] : 0,
+//     B[(j, c)][m] = in[pixel m shifted by tap j][c]
+// is one v_mfma_f32_16x16x32_f16 over 16 output pixels of one row.  1/16 of the MACs are useful, which still beats
+// the VALU by ~3x, and the B fragment is a single conflict-free ds_read_b128 of the halo tile: bits 1-3 of a pixel's
+// 16-byte slot index are XOR-ed with its halo column, bit 0 (the channel half, = lane bit 4) stays, which keeps the
+// 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) on 16 different slots for all 7 shifts.  A wave owns one 16-channel group per 128-channel slab and keeps the
+// 28 A fragments (4 row pairs x 7 kw) in registers; a B fragment (rows r, r+1) is shared by the output rows t and
+// t+2 (tap pairs kp and kp-1).  Output tile 16 x 4 pixels, slabs double-buffered by LDS-DMA as above.
+template <int NSLAB, int NBUF>
+__global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ lnw,
+                                                              const float* __restrict__ lnb, half_t* __restrict__ y,
+                                                              int H, int W, int C, float eps, int dbg) {
+    constexpr int TW = 16, TH = 4, R = 3, IW = TW + 6, IH = TH + 6, NPX = IW * IH;
+    constexpr int IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
+    constexpr int BUF = (IN_INSTR + W_INSTR) * 1024;   // halo tile directly followed by the taps (see row 10 below)
+    constexpr bool PIPE = NBUF == 2;   // two workgroups per CU hide the LDS latency by themselves
+    constexpr int ROWB = IW * 256;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
+    const int par_bytes = ((3 * C * 4 + 1023) / 1024) * 1024;
+    const float* par_s = reinterpret_cast<const float*>(dsm + NBUF * BUF);
+    float* red_s = reinterpret_cast<float*>(dsm + NBUF * BUF + par_bytes);   // [8 waves][64 px]
+    float* stat_s = red_s + 8 * 64;                                          // [64 px]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tpr = W / TW, tpi = tpr * (H / TH);
+    const int b = blockIdx.x / tpi, tin = blockIdx.x - b * tpi;
+    const int h0 = (tin / tpr) * TH, w0 = (tin % tpr) * TW;
+    const half_t* xb = x + (long)b * H * W * C;
+    const half_t* zero = reinterpret_cast<const half_t*>(gp_zero_page_tu);
+
+    auto issue = [&](int s, int buf) {
+        const unsigned base = lds0 + buf * BUF;
+        for (int ins = wave; ins < IN_INSTR; ins += 8) {
+            const int i = ins * 64 + lane, px = i >> 4, ps = i & 15;
+            const int iy = px / IW, ix = px - iy * IW;
+            const int gy = h0 - R + iy, gx = w0 - R + ix;
+            const int ls = ps ^ ((ix & 7) << 1);
+            const half_t* src = zero;
+            if (px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                src = xb + ((long)gy * W + gx) * C + s * 128 + ls * 8;
+            glds16_n(src, base + ins * 1024);
+        }
+        for (int ins = wave; ins < W_INSTR; ins += 8) {
+            const int i = ins * 64 + lane, tap = i >> 4, sl = i & 15;
+            const half_t* src = tap < 49 ? wt + (long)tap * C + s * 128 + sl * 8 : zero;
+            glds16_n(src, base + (IN_INSTR + ins) * 1024);
+        }
+    };
+    {
+        const int pin = par_bytes / 1024;
+        for (int ins = wave; ins < pin; ins += 8) {
+            const int f = (ins * 64 + lane) * 4;
+            const float* src = f < C ? bias + f : (f < 2 * C ? lnw + (f - C) : (f < 3 * C ? lnb + (f - 2 * C) : reinterpret_cast<const float*>(gp_zero_page_tu)));
+            glds16_n(src, lds0 + NBUF * BUF + ins * 1024);
+        }
+    }
+    if (dbg != 6) issue(0, 0);
+
+    // lane roles: A row / D channel-quad n4, B column / D pixel m, k-chunk q (tap j = q>>1, channel half q&1)
+    const int m = lane & 15, q = lane >> 4, jt = q >> 1;
+    const int lslot = wave * 2 + (q & 1);
+    unsigned sw[7];   // byte offset of this lane's B chunk for shift kw, row 0 (+ the second tap's row)
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw)
+        sw[kw] = (m + kw) * 256 + ((lslot ^ (((m + kw) & 7) << 1)) << 4) + jt * ROWB;
+    const int pos = m & 7;
+    const bool a_lane = (q & 1) == (m >> 3);
+    unsigned mk[4], mk3[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        mk[v] = (a_lane && v == (pos >> 1)) ? 0xffffffffu : 0u;
+        mk3[v] = jt ? 0u : mk[v];
+    }
+    const int sh = 16 * (pos & 1);
+
+    f32x4 acc[NSLAB][TH];
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+        for (int t = 0; t < TH; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (NBUF == 2 && s + 1 < NSLAB && dbg != 6) issue(s + 1, (s + 1) & 1);
+        const char* in_s = dsm + (s & (NBUF - 1)) * BUF;
+        const char* w_s = in_s + IN_INSTR * 1024;
+        union Frag { uint4 u; half8 h; };
+        // software pipeline over the 7 column shifts: the 4 A fragments and 10 B rows of shift kw+1 are fetched
+        // while the 16 MFMAs of shift kw run.  Rows r, r+1 of the halo tile feed output row t with tap pair kp
+        // whenever t + 2 kp == r.  Row 10 (only met with the all-zero half of the kp == 3 fragment) lies in the tap
+        // area behind the tile: finite data.
+        Frag af[PIPE ? 2 : 1][4], bf[PIPE ? 2 : 1][TH + 6];
+        unsigned wraw[4];
+        auto fetch = [&](int kw, int slot) {   // LDS reads only: the VALU part (build) must not sit in front of the MFMAs
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const int kh = 2 * kp + jt;
+                const int tap = (kh < 7 ? kh : 6) * 7 + kw;
+                wraw[kp] = *reinterpret_cast<const unsigned short*>(w_s + tap * 256 + (wave * 16 + m) * 2);
+            }
+#pragma unroll
+            for (int r = 0; r < TH + 6; ++r)
+                bf[slot][r].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + r * ROWB);
+        };
+        auto build = [&](int slot) {
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                const unsigned u = wraw[kp] << sh;
+                af[slot][kp].u = kp == 3 ? uint4{u & mk3[0], u & mk3[1], u & mk3[2], u & mk3[3]}
+                                         : uint4{u & mk[0], u & mk[1], u & mk[2], u & mk[3]};
+            }
+        };
+        if (PIPE) { fetch(0, 0); build(0); }
+#pragma unroll
+        for (int kw = 0; kw < (dbg == 5 ? 0 : 7); ++kw) {
+            if (!PIPE) { fetch(kw, 0); build(0); }
+            else if (kw + 1 < 7) fetch(kw + 1, (kw + 1) & 1);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < TH + 6; ++r)
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) {
+                    const int t = r - 2 * kp;
+                    if (t >= 0 && t < TH)
+                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[PIPE ? kw & 1 : 0][kp].h, bf[PIPE ? kw & 1 : 0][r].h, acc[s][t], 0, 0, 0);
+                }
+            if (PIPE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kw + 1 < 7) build((kw + 1) & 1);
+            }
+        }
+        if (NBUF == 1 && s + 1 < NSLAB) {
+            __syncthreads();
+            if (dbg != 6) issue(s + 1, 0);
+        }
+    }
+
+    // D layout: lane holds channels cbase + 4 q + {0..3} of pixel (t, m).  Bias, then LayerNorm over C.
+    const int cq = wave * 16 + q * 4;
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        const float4 bv = *reinterpret_cast<const float4*>(par_s + s * 128 + cq);
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            acc[s][t][0] += bv.x; acc[s][t][1] += bv.y; acc[s][t][2] += bv.z; acc[s][t][3] += bv.w;
+        }
+    }
+    const float invC = 1.0f / C;
+    float mean[TH], rstd[TH];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (pass == 1) acc[s][t][e] -= mean[t];
+                    a += pass == 0 ? acc[s][t][e] : acc[s][t][e] * acc[s][t][e];
+                }
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            if (q == 0) red_s[wave * 64 + t * 16 + m] = a;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) a += red_s[w8 * 64 + tid];
+            stat_s[tid] = pass == 0 ? a * invC : rsqrtf(a * invC + eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            if (pass == 0) mean[t] = stat_s[t * 16 + m];
+            else rstd[t] = stat_s[t * 16 + m];
+        }
+    }
+    // normalised rows go through LDS (the DMA buffers are free now) so that the global stores are 16 B per lane and
+    // 1 KB contiguous per pixel; 16-byte chunks of a pixel are XOR-swizzled with the pixel index.
+    char* out_s = dsm;
+#pragma unroll
+    for (int s = 0; s < NSLAB; ++s) {
+        const float4 gw = *reinterpret_cast<const float4*>(par_s + C + s * 128 + cq);
+        const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 128 + cq);
+        const int chunk = s * 16 + wave * 2 + (q >> 1);
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            half4 o;
+            o[0] = (_Float16)(acc[s][t][0] * rstd[t] * gw.x + gb.x);
+            o[1] = (_Float16)(acc[s][t][1] * rstd[t] * gw.y + gb.y);
+            o[2] = (_Float16)(acc[s][t][2] * rstd[t] * gw.z + gb.z);
+            o[3] = (_Float16)(acc[s][t][3] * rstd[t] * gw.w + gb.w);
+            const int px = t * 16 + m;
+            *reinterpret_cast<half4*>(out_s + px * (C * 2) + ((chunk ^ m) << 4) + (q & 1) * 8) = o;
+        }
+    }
+    __syncthreads();
+    const int cpp = C / 8;   // 16-byte chunks per pixel
+    for (int i = tid; i < 64 * cpp; i += 512) {
+        const int px = i / cpp, c = i - px * cpp;
+        const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
+        const int t = px >> 4, mm = px & 15;
+        *reinterpret_cast<uint4*>(y + (((long)b * H + h0 + t) * W + w0 + mm) * C + c * 8) = v;
+    }
+}
+
+template <int NSLAB, int NBUF>
+void launch_dw7_mfma(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B,
+                     int H, int W, int C, float eps, hipStream_t s, int dbg) {
+    constexpr int NPX = 22 * 10, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
+    const int LDS = NBUF * (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024 + 9 * 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_mfma_kernel<NSLAB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dwconv7_ln_mfma_kernel<NSLAB, NBUF>), dim3(B * (H / 4) * (W / 16)), dim3(512), LDS, s, (const half_t*)x,
+                       (const half_t*)wt, bias, lnw, lnb, (half_t*)y, H, W, C, eps, dbg);
+}
+
 // ---------------------------------------------------------------------------- row LayerNorm
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -588,6 +820,14 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && H % 4 == 0 && W % 16 == 0 &&
+        (C == 128 || C == 256 || C == 512)) {
+        if (C == 128) launch_dw7_mfma<1, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+        else if (C == 256) launch_dw7_mfma<2, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+        else if ((long)B * (H / 4) * (W / 16) >= 512) launch_dw7_mfma<4, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+        else launch_dw7_mfma<4, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+        GP_LAUNCH_CHECK("gp_dwconv_ln");
+    }
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && H % 8 == 0 && W % 8 == 0) {
         const int nslab = C / (16 * (16 / esz));
         bool done = true;

@@ -208,7 +208,7 @@ def test_dcnv3_generic_geometry_and_errors():
 
 # ----------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("C,H,KS", [(128, 16, 7), (512, 8, 7), (1024, 8, 7), (256, 16, 3)])
+@pytest.mark.parametrize("C,H,KS", [(128, 16, 7), (256, 32, 7), (512, 16, 7), (512, 8, 7), (1024, 8, 7), (256, 16, 3)])
 def test_dwconv_ln(dt, C, H, KS):
     o = ops()
     B = 2
