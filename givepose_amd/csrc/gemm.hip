@@ -338,6 +338,91 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmKP p) {
 // Epilogue: each wave transposes its accumulators through a private 8 KB LDS slab (32 rows x 64 fp32,
 // XOR-swizzled) so that global stores/residual loads are whole 128-B row segments.
 
+// ---- lean epilogue of the large-tile kernels: fp16 output, tile fully inside C.
+// The activation runs in the MFMA register layout (lane = 4 consecutive n of one m, so bias / gamma are 4 registers
+// per n-tile), the result is packed to fp16 BEFORE the transpose (half the LDS bytes of the fp32 slab), rows are
+// read back 16 B per lane and stored 8 rows x 128 B per wave instruction; the residual (fp16, prefetched ahead of
+// the first store) is added with packed fp16 adds.  EPI is a template parameter: the run-time switch of the generic
+// epilogue below cost more (branches around every 4-element group) than its arithmetic.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][MT], char* slab, int mb, int nb, int lane) {
+    constexpr int PITCH = 144, NH = MT / 4;   // 64 rows x (128 B + 16 B pad) per wave and half tile
+    constexpr bool RES = EPI == GP_EPI_SCALE_RES || EPI == GP_EPI_RES_RELU;
+    const int fr = lane & 15, fq = lane >> 4, rr = lane >> 3, rc = lane & 7;
+    f32x4 b4[NT], g4[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nb + nt * 16 + fq * 4;
+        b4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g4[nt] = EPI == GP_EPI_SCALE_RES ? *reinterpret_cast<const f32x4*>(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    half8 rres[RES ? NH : 1][8];
+    if constexpr (RES) {
+        const half_t* R = reinterpret_cast<const half_t*>(p.res);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                rres[h][i] = *reinterpret_cast<const half8*>(R + (long)(mb + h * 64 + i * 8 + rr) * p.ldres + nb + rc * 8);
+    }
+    half_t* C = reinterpret_cast<half_t*>(p.C);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float gs[NT], gq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) gs[nt] = gq[nt] = 0.f;
+#pragma unroll
+        for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v = acc[nt][h * 4 + ml] + b4[nt];
+                if constexpr (EPI == GP_EPI_GELU) {
+                    const f32x2 lo = gelu_poly2(f32x2{v[0], v[1]}), hi = gelu_poly2(f32x2{v[2], v[3]});
+                    v = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                } else if constexpr (EPI == GP_EPI_RELU) {
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                } else if constexpr (EPI == GP_EPI_LRELU) {
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.1f * v[j];
+                } else if constexpr (EPI == GP_EPI_SCALE_RES) {
+                    v *= g4[nt];
+                }
+                if (!RES && p.gn_partial) {
+                    gs[nt] += (v[0] + v[1]) + (v[2] + v[3]);
+                    gq[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+                half4 o;
+                for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+                *reinterpret_cast<half4*>(slab + (ml * 16 + fr) * PITCH + (nt * 4 + fq) * 8) = o;
+            }
+        if (!RES && p.gn_partial) {   // fused GroupNorm statistics: (sum, sum of squares) per 64 rows and channel group
+            const int mrow = mb + h * 64;
+            const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
+            const int b = mrow / p.gn_hw, ch = (mrow - b * p.gn_hw) >> 6;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float a = gs[nt], q = gq[nt];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+                if (p.gn_cpg == 8) { a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64); }
+                if (fr == 0 && (p.gn_cpg == 4 || (fq & 1) == 0)) {
+                    float* o = p.gn_partial + (((long)b * cpi + ch) * G + (nb + nt * 16 + fq * 4) / p.gn_cpg) * 2;
+                    o[0] = a;
+                    o[1] = q;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + rr;
+            half8 v = *reinterpret_cast<const half8*>(slab + row * PITCH + rc * 16);
+            if constexpr (RES) v += rres[h][i];
+            if constexpr (EPI == GP_EPI_RES_RELU) v = __builtin_elementwise_max(v, half8{0, 0, 0, 0, 0, 0, 0, 0});
+            if (p.dbg != 4 || (float)v[0] == 12345.0f)
+                *reinterpret_cast<half8*>(C + (long)(mb + h * 64 + row) * p.ldc + nb + rc * 8) = v;
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) char lds_char_t;
 
 // One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr, +1 KB).
@@ -355,7 +440,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128>
-__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP p) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -571,6 +656,34 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
     }
     }
 
+    if (p.dbg == 3) {   // timing ablation: no epilogue (keeps the accumulators alive, stores nothing in practice)
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (s == 12345.678f) reinterpret_cast<float*>(p.C)[0] = s;
+        return;
+    }
+    if constexpr (sizeof(T) == 2) {
+        const bool res_epi = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
+        const bool lean = !p.out_f32 && p.dbg != 5 && m0 + BM <= p.M && n0 + BN <= p.N && p.ldc % 8 == 0 &&
+                          ((size_t)p.C & 15) == 0 && !(res_epi && (p.gn_partial || p.ldres % 8 || ((size_t)p.res & 15)));
+        if (lean) {
+            static_assert(NS * STAGE >= NW * 9216, "lean epilogue slabs must fit");
+            char* slab = smem + wave * 9216;
+            const int mb = m0 + wm * MT * 16, nb = n0 + wn * NT * 16;
+            switch (p.epi) {
+                case GP_EPI_GELU: epilogue_lean<MT, NT, GP_EPI_GELU>(p, acc, slab, mb, nb, lane); break;
+                case GP_EPI_RELU: epilogue_lean<MT, NT, GP_EPI_RELU>(p, acc, slab, mb, nb, lane); break;
+                case GP_EPI_LRELU: epilogue_lean<MT, NT, GP_EPI_LRELU>(p, acc, slab, mb, nb, lane); break;
+                case GP_EPI_SCALE_RES: epilogue_lean<MT, NT, GP_EPI_SCALE_RES>(p, acc, slab, mb, nb, lane); break;
+                case GP_EPI_RES_RELU: epilogue_lean<MT, NT, GP_EPI_RES_RELU>(p, acc, slab, mb, nb, lane); break;
+                default: epilogue_lean<MT, NT, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
+            }
+            return;
+        }
+    }
     // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
     //      Lane owns output columns n .. n+3 (fixed) of rows i*4 + (lane>>4); every global load (bias, gamma,
     //      the whole residual tile in f16 mode) is issued before the first store.
@@ -621,7 +734,7 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_big_kernel(const GemmKP 
                 const int m = mb + j * 32 + row;
                 if (m < p.M && nok) {
                     const f32x4 o = epi_apply<T>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
-                    store4<T>(p, m, en, o);
+                    if (p.dbg != 4 || o[0] == 12345.678f) store4<T>(p, m, en, o);
                     gsum += (o[0] + o[1]) + (o[2] + o[3]);
                     gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
                 }
@@ -713,17 +826,18 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     int variant = d->variant % 10;
     p.dbg = d->variant / 10;
     if (variant == 0) {
-        // measured per shape (scripts/gemm_bench.py, profiles/r01b): 256x256 wins when it fills the chip and N is a
-        // multiple of 256; otherwise 128x128 LDS-DMA at two workgroups per CU; split-K stays on the register-staged kernel
+        // measured per shape (scripts/gemm_bench.py): with the lean epilogue the 256x128 tile at two workgroups per CU
+        // (8) beats 256x256 (6) wherever that filled the chip (N % 256 == 0, >= 192 tiles of 256x256); otherwise
+        // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
-        else if (p.gn_partial) variant = (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) ? 6 : (d->dtype == GP_F16 ? 7 : 4);
-        else if (d->dtype == GP_F16 && d->N % 256 == 0 && tA >= 192) variant = 6;  // (fp32 256x256 spills)
-        else variant = d->dtype == GP_F16 ? 7 : 4;   // 6 / 7 = software-pipelined schedule (+3..16 % in one-process A/B)
+        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && tA >= 192) ? 8 : 7;
+        else variant = 4;
     }
     GP_REQUIRE(variant >= 1 && variant <= 9 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
-    if (variant == 8) {   // 256x256, 64-byte K steps, 4-stage ring (3 steps of DMA in flight)
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+    if (variant == 8) {   // 256x128, 4 waves of 128x64, 64-byte K steps, 3-stage ring: two workgroups per CU, so the
+                          // epilogue of one overlaps the main loop of the other (short-K, store-heavy shapes)
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 9) {   // 128x128, 64-byte K steps, 4-stage ring, two workgroups per CU
