@@ -79,27 +79,30 @@ __device__ __forceinline__ float fast_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 
-// GELU for fp16 storage: erf(z) ~ clamp(z * P(z^2)), z clamped to +-3.1, P of degree 8 (weighted least squares
-// fit, scripts: DESIGN.md section 5); max |GELU error| 3.8e-5 in fp32 Horner = 1/13 of an fp16 ulp at |x| ~ 1.
+// GELU for fp16 storage: erf(x / sqrt 2) ~ xc * r(xc^2), xc = x clamped to +-4.4, r of degree 8 (minimax LP fit,
+// DESIGN.md section 5); max |GELU error| 4.1e-5 in fp32 Horner = 1/12 of an fp16 ulp at |x| ~ 1.
 // No transcendental, and written on 2-vectors so that hipcc emits v_pk_{mul,fma,max,min}_f32: a wave64 VALU
 // instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the fc1 epilogues and the
 // GroupNorm+GELU passes VALU bound.  The fp32 storage path keeps gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
-    const f32x2 lim = {3.1f, 3.1f}, one = {1.f, 1.f};
-    f32x2 z = x * 0.70710678118654752440f;
-    z = __builtin_elementwise_min(__builtin_elementwise_max(z, -lim), lim);
-    const f32x2 t = z * z;
-    f32x2 p = {2.617556483e-08f, 2.617556483e-08f};
-    p = __builtin_elementwise_fma(p, t, f32x2{-1.372215252e-06f, -1.372215252e-06f});
-    p = __builtin_elementwise_fma(p, t, f32x2{3.173028381e-05f, 3.173028381e-05f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-4.296133993e-04f, -4.296133993e-04f});
-    p = __builtin_elementwise_fma(p, t, f32x2{3.825224470e-03f, 3.825224470e-03f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-2.390606701e-02f, -2.390606701e-02f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.091638282e-01f, 1.091638282e-01f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-3.738503158e-01f, -3.738503158e-01f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.127893329e+00f, 1.127893329e+00f});
-    f32x2 e = __builtin_elementwise_min(__builtin_elementwise_max(z * p, -one), one);
+    // erf(x / sqrt 2) = xc * r(xc^2), xc = clamp(x, +-4.4); r: degree-8 minimax (LP fit, weighted by the GELU error
+    // x^2 / 2, constrained to meet erf at the clamp so that no second clamp is needed: beyond it the result is
+    // x * (1 - 5.4e-6) resp. x * 5.4e-6).  7 VALU ops per element: 2 v_med3 + 12 packed ops per pair.
+    f32x2 xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.4f, 4.4f);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.4f, 4.4f);
+    const f32x2 t = xc * xc;
+    f32x2 p = {6.9778819482e-11f, 6.9778819482e-11f};
+    p = __builtin_elementwise_fma(p, t, f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
+    p = __builtin_elementwise_fma(p, t, f32x2{3.4381198132e-07f, 3.4381198132e-07f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-9.3718131897e-06f, -9.3718131897e-06f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.6778340171e-04f, 1.6778340171e-04f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-2.1052074914e-03f, -2.1052074914e-03f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.9270481587e-02f, 1.9270481587e-02f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-1.3212860816e-01f, -1.3212860816e-01f});
+    p = __builtin_elementwise_fma(p, t, f32x2{7.9751050727e-01f, 7.9751050727e-01f});
+    const f32x2 e = xc * p;
     const f32x2 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
 }

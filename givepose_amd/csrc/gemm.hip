@@ -349,11 +349,10 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
     constexpr int PITCH = 144, NH = MT / 4;   // 64 rows x (128 B + 16 B pad) per wave and half tile
     constexpr bool RES = EPI == GP_EPI_SCALE_RES || EPI == GP_EPI_RES_RELU;
     const int fr = lane & 15, fq = lane >> 4, rr = lane >> 3, rc = lane & 7;
-    f32x4 b4[NT], g4[NT];
+    f32x4 g4[NT];   // (the bias is already in the accumulators)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nb + nt * 16 + fq * 4;
-        b4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         g4[nt] = EPI == GP_EPI_SCALE_RES ? *reinterpret_cast<const f32x4*>(p.gamma + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
     half8 rres[RES ? NH : 1][8];
@@ -375,7 +374,7 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
         for (int ml = 0; ml < 4; ++ml)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                f32x4 v = acc[nt][h * 4 + ml] + b4[nt];
+                f32x4 v = acc[nt][h * 4 + ml];
                 if constexpr (EPI == GP_EPI_GELU) {
                     const f32x2 lo = gelu_poly2(f32x2{v[0], v[1]}), hi = gelu_poly2(f32x2{v[2], v[3]});
                     v = f32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -528,11 +527,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * RB : zp, ws + i * NW * 1024);
     };
 
+    // the lean epilogue (fp16 output, tile fully inside C: see epilogue_lean) takes the bias as the initial value of
+    // the accumulators: in the MFMA register layout it is 4 registers per n-tile, and the add leaves the epilogue
+    bool lean = false;
+    if constexpr (sizeof(T) == 2) {
+        const bool res_epi = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
+        lean = !p.out_f32 && p.dbg != 5 && m0 + BM <= p.M && n0 + BN <= p.N && p.ldc % 8 == 0 &&
+               ((size_t)p.C & 15) == 0 && !(res_epi && (p.gn_partial || p.ldres % 8 || ((size_t)p.res & 15)));
+    }
     f32x4 acc[NT][MT];
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < NT; ++a) {
+        f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lean && p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * NT * 16 + a * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MT; ++b) acc[a][b] = init;
+    }
 
     const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
     const int xfo = (wm * MT * 16 + fr) * RB, wfo = (wn * NT * 16 + fr) * RB;
@@ -666,9 +676,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         return;
     }
     if constexpr (sizeof(T) == 2) {
-        const bool res_epi = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
-        const bool lean = !p.out_f32 && p.dbg != 5 && m0 + BM <= p.M && n0 + BN <= p.N && p.ldc % 8 == 0 &&
-                          ((size_t)p.C & 15) == 0 && !(res_epi && (p.gn_partial || p.ldres % 8 || ((size_t)p.res & 15)));
         if (lean) {
             static_assert(NS * STAGE >= NW * 9216, "lean epilogue slabs must fit");
             char* slab = smem + wave * 9216;
