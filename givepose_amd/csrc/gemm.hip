@@ -848,7 +848,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 9) {   // 128x128, 64-byte K steps, 4-stage ring, two workgroups per CU
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 4, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 4, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);   // experiment: as 8 with 4 stages = 96 KB LDS = one workgroup per CU
         GP_LAUNCH_CHECK("gp_gemm");
     }
     GP_REQUIRE(!(p.gn_partial && variant == 1), "gp_gemm: fused GroupNorm needs a large-tile variant");

@@ -87,6 +87,33 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x
     store16<T>(y + ((b * Ho + oy) * Wo + ox) * C + cs * VEC, o);
 }
 
+// Row-mapped form (C / VEC a power of two): blockIdx.y = output row, blockIdx.z = image, so the vertical taps are
+// wave-uniform and no 64-bit div / mod is left per thread -- the flat form above spends ~2/3 of its VALU time on
+// index arithmetic and is VALU bound at 2.9 TB/s (scripts/gn_bench.py).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W,
+                                                              int C, int ct_shift) {
+    constexpr int VEC = Vec16<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W, CT = 1 << ct_shift;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ox = i >> ct_shift, cs = i & (CT - 1);
+    if (ox >= Wo) return;
+    const int oy = blockIdx.y, b = blockIdx.z;
+    const float sy = (float)(H - 1) / (float)(Ho - 1) * oy, sx = (float)(W - 1) / (float)(Wo - 1) * ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const T* r0 = x + ((long)(b * H + y0) * W) * C + cs * VEC;
+    const T* r1 = x + ((long)(b * H + y1) * W) * C + cs * VEC;
+    const Vec16<T> v00 = load16<T>(r0 + x0 * C), v01 = load16<T>(r0 + x1 * C), v10 = load16<T>(r1 + x0 * C),
+                   v11 = load16<T>(r1 + x1 * C);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+        o.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
+    store16<T>(y + (((long)(b * Ho + oy)) * Wo + ox) * C + cs * VEC, o);
+}
+
 // ------------------------------------------------------------------------------------- deconv col2im
 // out[b][y][x][co] = sum over (ky,kx) with y = 2i-1+ky, x = 2j-1+kx of cols[(b,i,j)][(ky*3+kx)*C + co]
 template <typename T>
@@ -544,6 +571,15 @@ extern "C" int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int 
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * 4 * H * W * (C / vec);
     gp_timing_before(s, GP_KC_ELEMENTWISE, 8.0 * total * vec, (double)B * H * W * C * esz * 5);
+    const int ct = C / vec;
+    if ((ct & (ct - 1)) == 0 && 2 * H <= 65535 && B <= 65535) {
+        int sh = 0;
+        while ((1 << sh) < ct) ++sh;
+        dim3 grid(cdiv((long)2 * W * ct, 256), 2 * H, B);
+        if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_rows_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, H, W, C, sh);
+        else hipLaunchKernelGGL(upsample2x_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, sh);
+        GP_LAUNCH_CHECK("gp_upsample_bilinear2x");
+    }
     if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, B, H, W, C);
     else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
     GP_LAUNCH_CHECK("gp_upsample_bilinear2x");

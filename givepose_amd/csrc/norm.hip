@@ -583,6 +583,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 // ---------------------------------------------------------------------------- GroupNorm
 // pixels per block: 256 when that still gives >= 1024 blocks, else 64 (small maps are latency bound)
 static inline int gn_pxb(int B, int HW) { return ((long)B * HW / 256 >= 1024 || HW < 64) ? 256 : 64; }
+// pixels per workgroup of the apply kernels (independent of the statistics chunks): small enough for >= 8 workgroups
+// per CU at bs = 64, so that one workgroup's statistics finalize / VALU phase overlaps the others' streaming
+static inline int gn_apply_pxb(int B, int HW) {
+    int pxb = gn_pxb(B, HW);
+    while (pxb > 32 && (long)B * cdiv(HW, pxb) < 2048) pxb >>= 1;
+    return pxb;
+}
 
 // partial[((b*chunks + chunk)*G + g)*2 + {0,1}] = (sum, sum of squares) of this chunk, fixed order
 template <typename T>
@@ -634,6 +641,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
 }
 
+// (mean, rstd) of every group of image b from the chunk partials, into st[g][0..1]; ends with a barrier.
+// All 256 threads take part: thread t sums the chunks c = t / G, t / G + 256 / G, ... of group t % G (fixed order),
+// the 256 / G slices are added in fixed order through LDS.  The first version let thread g walk all chunks alone:
+// 64 dependent L2 round trips (~40 us) in front of every 64x64 GroupNorm apply.
+__device__ __forceinline__ void gn_finalize(const float* __restrict__ partial, int b, int chunks, int G, float inv_count,
+                                            float eps, float (*st)[2]) {
+    __shared__ double fin[256][2];
+    const int g = threadIdx.x % G, sl = threadIdx.x / G, nsl = 256 / G;
+    double a = 0.0, q = 0.0;
+    for (int c = sl; c < chunks; c += nsl) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(partial + (((long)b * chunks + c) * G + g) * 2);
+        a += v[0];
+        q += v[1];
+    }
+    fin[threadIdx.x][0] = a;
+    fin[threadIdx.x][1] = q;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        a = 0.0; q = 0.0;
+        for (int i = 0; i < nsl; ++i) {
+            a += fin[i * G + threadIdx.x][0];
+            q += fin[i * G + threadIdx.x][1];
+        }
+        const double mean = a * inv_count;
+        double var = q * inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[threadIdx.x][0] = (float)mean;
+        st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
                                                        const float* __restrict__ w, const float* __restrict__ bb,
@@ -644,41 +683,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
     const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
     const int b = blockIdx.y;
-    if (threadIdx.x < G) {  // finalize (mean, rstd) of group threadIdx.x from the chunk partials, fixed order
-        double a = 0.0, q = 0.0;
-        for (int c = 0; c < chunks; ++c) {
-            const float* p = partial + (((long)b * chunks + c) * G + threadIdx.x) * 2;
-            a += p[0];
-            q += p[1];
-        }
-        const double mean = a * inv_count;
-        double var = q * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        st[threadIdx.x][0] = (float)mean;
-        st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
     const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
-    float sc[VEC], sh[VEC];
-    {
-        float gw[VEC], gb[VEC];
-        load_f32<T>(w + cs * VEC, gw);
-        load_f32<T>(bb + cs * VEC, gb);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int g = (cs * VEC + e) / cpg;
-            sc[e] = st[g][1] * gw[e];
-            sh[e] = gb[e] - st[g][0] * sc[e];
-        }
-    }
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
     T* yb = y + ((long)b * HW) * ldy + cs * VEC;
-    // 4 pixels in flight per thread: the loop is otherwise one dependent HBM round trip per pixel
+    // 4 pixels in flight per thread (the loop is otherwise one dependent HBM round trip per pixel); the first four
+    // and the affine parameters are requested before the statistics are finalised, whose loads they then overlap
+    Vec16<T> v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (p0 + pl + u * PG < p1) v[u] = load16<T>(xb + (long)(p0 + pl + u * PG) * C);
+    float gw[VEC], gb[VEC];
+    load_f32<T>(w + cs * VEC, gw);
+    load_f32<T>(bb + cs * VEC, gb);
+    gn_finalize(partial, b, chunks, G, inv_count, eps, st);
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (cs * VEC + e) / cpg;
+        sc[e] = st[g][1] * gw[e];
+        sh[e] = gb[e] - st[g][0] * sc[e];
+    }
     for (int pb = p0 + pl; pb < p1; pb += 4 * PG) {
-        Vec16<T> v[4];
+        Vec16<T> cur[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = v[u];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (pb + u * PG < p1) v[u] = load16<T>(xb + (long)(pb + u * PG) * C);
+            if (pb + (4 + u) * PG < p1) v[u] = load16<T>(xb + (long)(pb + (4 + u) * PG) * C);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = pb + u * PG;
@@ -687,13 +718,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                 for (int e = 0; e < VEC; e += 2) {
-                    const f32x2 g = gelu_poly2(f32x2{v[u].get(e) * sc[e] + sh[e], v[u].get(e + 1) * sc[e + 1] + sh[e + 1]});
+                    const f32x2 g = gelu_poly2(f32x2{cur[u].get(e) * sc[e] + sh[e], cur[u].get(e + 1) * sc[e + 1] + sh[e + 1]});
                     o.set(e, g[0]);
                     o.set(e + 1, g[1]);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(v[u].get(e) * sc[e] + sh[e], act));
+                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(cur[u].get(e) * sc[e] + sh[e], act));
             }
             store16<T>(yb + (long)p * ldy, o);
         }
@@ -716,45 +747,38 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
     const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
     const int b = blockIdx.y;
-    if (threadIdx.x < G) {
-        double a = 0.0, q = 0.0;
-        for (int c = 0; c < chunks; ++c) {
-            const float* p = partial + (((long)b * chunks + c) * G + threadIdx.x) * 2;
-            a += p[0];
-            q += p[1];
-        }
-        const double mean = a * inv_count;
-        double var = q * inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        st[threadIdx.x][0] = (float)mean;
-        st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
     const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
-    float sc[VEC], sh[VEC], w0[VEC], w1[VEC], w2[VEC];
-    {
-        float gw[VEC], gb[VEC];
-        load_f32<T>(w + cs * VEC, gw);
-        load_f32<T>(bb + cs * VEC, gb);
-        load_f32<T>(ow + cs * VEC, w0);
-        load_f32<T>(ow + C + cs * VEC, w1);
-        load_f32<T>(ow + 2 * C + cs * VEC, w2);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const int g = (cs * VEC + e) / cpg;
-            sc[e] = st[g][1] * gw[e];
-            sh[e] = gb[e] - st[g][0] * sc[e];
-        }
-    }
-    const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
     const int iters = (GN_PXB + PG - 1) / PG;   // uniform trip count: the reduction below needs every thread
-    for (int it0 = 0; it0 < iters; it0 += 4) {          // 4 pixels in flight per thread, statically indexed
+    Vec16<T> vn[4];                             // 4 pixels in flight per thread, statically indexed; first four
+#pragma unroll                                  // requested ahead of the statistics finalize
+    for (int u = 0; u < 4; ++u) {
+        const int p = p0 + pl + u * PG;
+        if (u < iters && p < p1) vn[u] = load16<T>(xb + (long)p * C);
+    }
+    float sc[VEC], sh[VEC], w0[VEC], w1[VEC], w2[VEC];
+    float gw[VEC], gb[VEC];
+    load_f32<T>(w + cs * VEC, gw);
+    load_f32<T>(bb + cs * VEC, gb);
+    load_f32<T>(ow + cs * VEC, w0);
+    load_f32<T>(ow + C + cs * VEC, w1);
+    load_f32<T>(ow + 2 * C + cs * VEC, w2);
+    const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
+    gn_finalize(partial, b, chunks, G, inv_count, eps, st);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int g = (cs * VEC + e) / cpg;
+        sc[e] = st[g][1] * gw[e];
+        sh[e] = gb[e] - st[g][0] * sc[e];
+    }
+    for (int it0 = 0; it0 < iters; it0 += 4) {
         Vec16<T> vq[4];
 #pragma unroll
+        for (int u = 0; u < 4; ++u) vq[u] = vn[u];
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = p0 + pl + (it0 + u) * PG;
-            if (it0 + u < iters && p < p1) vq[u] = load16<T>(xb + (long)p * C);
+            const int p = p0 + pl + (it0 + 4 + u) * PG;
+            if (it0 + 4 + u < iters && p < p1) vn[u] = load16<T>(xb + (long)p * C);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -902,7 +926,7 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
-    const int pxb = gn_pxb(B, HW), chunks = chunks_in > 0 ? chunks_in : cdiv(HW, pxb);
+    const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW)), pxb = gn_apply_pxb(B, HW);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
     if (dtype == GP_F16)
@@ -921,7 +945,7 @@ extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const
     GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_apply_xyz: unsupported C=%d G=%d", C, G);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 10.0 * B * HW * C, (double)B * HW * (C * esz + 28));
-    const int pxb = gn_pxb(B, HW), chunks = chunks_in > 0 ? chunks_in : cdiv(HW, pxb);
+    const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW)), pxb = gn_apply_pxb(B, HW);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
     if (dtype == GP_F16)
