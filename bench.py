@@ -160,6 +160,60 @@ def main():
         line["kernel_classes"] = classes
         line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
 
+    # ---------------- H->D inclusive rate (never `value`): the boundary hands over host tensors, so time
+    # the same step with every input copied from pinned host memory first, copy and step serialised (no overlap)
+    if rank == 0 and not args.no_roofline:
+        net.use_graph = not args.no_graph
+        pinned = {k: torch.from_numpy(v).reshape(static[k].shape).to(static[k].dtype).pin_memory() for k, v in host.items()}
+        def step_h2d():
+            for k, v in pinned.items():
+                static[k].copy_(v, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            net.forward_device(static, dev)
+        for _ in range(3):
+            step_h2d()
+        torch.cuda.synchronize(dev)
+        n_h = max(5, min(args.steps, 20))
+        t0 = time.perf_counter()
+        for _ in range(n_h):
+            step_h2d()
+        torch.cuda.synchronize(dev)
+        hdt = time.perf_counter() - t0
+        line["h2d_inclusive"] = {"value": round(B * n_h / hdt, 2), "unit": "images/s (one rank)", "ms_per_step": round(hdt / n_h * 1e3, 4),
+                                 "host_bytes_per_step": int(sum(v.numel() * v.element_size() for v in pinned.values())),
+                                 "note": "pinned host -> HBM copy of all inputs, then the step; serialised"}
+        # same, with the crops made on the device (givepose_amd.preprocess / gp_crop_rois): uint8 frames
+        # (4 detections per 640x480 frame) + uint8 masks + boxes travel instead of fp32 crops
+        import numpy as np
+        from givepose_amd.preprocess import RoiCropper
+        rng = np.random.default_rng(0)
+        nf = (B + 3) // 4
+        frames_h = torch.from_numpy(rng.integers(0, 256, (nf, 480, 640, 3), dtype=np.uint8)).pin_memory()
+        masks_h = torch.from_numpy((rng.random((B, 480, 640)) > 0.5).astype(np.uint8)).pin_memory()
+        frames_d, masks_d = torch.empty_like(frames_h, device=dev), torch.empty_like(masks_h, device=dev)
+        y1, x1 = rng.integers(0, 200, B), rng.integers(0, 300, B)
+        boxes = np.stack([y1, x1, y1 + rng.integers(60, 260, B), x1 + rng.integers(60, 320, B)], axis=1)
+        fidx, midx = [i // 4 for i in range(B)], list(range(B))
+        cropper = RoiCropper(480, 640, dev)
+        def step_crop():
+            frames_d.copy_(frames_h, non_blocking=True)
+            masks_d.copy_(masks_h, non_blocking=True)
+            cropper(frames_d, masks_d, fidx, midx, boxes, out=static)
+            torch.cuda.current_stream(dev).synchronize()
+            net.forward_device(static, dev)
+        for _ in range(3):
+            step_crop()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_h):
+            step_crop()
+        torch.cuda.synchronize(dev)
+        cdt2 = time.perf_counter() - t0
+        line["h2d_inclusive_device_crop"] = {"value": round(B * n_h / cdt2, 2), "unit": "images/s (one rank)",
+                                             "ms_per_step": round(cdt2 / n_h * 1e3, 4),
+                                             "host_bytes_per_step": int(frames_h.numel() + masks_h.numel() + B * 120),
+                                             "note": "uint8 frames + masks + boxes -> HBM, gp_crop_rois, then the step; serialised"}
+
     # ---------------- CPU baseline: oracle on the host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import posenet_ref as O

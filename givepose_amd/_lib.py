@@ -55,6 +55,8 @@ PROTOTYPES = {
     "gp_resnet_stem": ([_P] * 4 + [c_int] * 4 + [_P], c_int),
     "gp_maxpool3x3s2": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_mask_resize_nearest": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "gp_crop_rois": ([_P] * 12 + [c_int] * 7 + [_P], c_int),
+    "gp_pred_rt": ([_P] * 6 + [c_int, _P], c_int),
     "gp_graph_begin": ([_P], c_int),
     "gp_graph_end": ([_P, POINTER(c_void_p)], c_int),
     "gp_graph_launch": ([_P, _P], c_int),

@@ -59,6 +59,63 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     }
 }
 
+
+// ------------------------------------------------------------------------------------- crop pre-processing
+// One thread per destination pixel of the S x S crop (image + mask) or of the R x R crop (coordinate grid); the
+// fixed-point source coordinate is cv::warpAffine's (AB_BITS = 10, round-half-even of the double products).
+__device__ __forceinline__ bool warp_src(const double* __restrict__ m, int x, int y, int W, int H, int& X, int& Y) {
+    const int X0 = __double2int_rn((m[1] * y + m[2]) * 1024.0) + 512, Y0 = __double2int_rn((m[4] * y + m[5]) * 1024.0) + 512;
+    X = (X0 + __double2int_rn(m[0] * x * 1024.0)) >> 10;
+    Y = (Y0 + __double2int_rn(m[3] * x * 1024.0)) >> 10;
+    return (unsigned)X < (unsigned)W && (unsigned)Y < (unsigned)H;
+}
+
+__global__ __launch_bounds__(256) void crop_rois_kernel(const unsigned char* __restrict__ frames,
+                                                        const unsigned char* __restrict__ masks,
+                                                        const int* __restrict__ frame_idx, const int* __restrict__ mask_idx,
+                                                        const double* __restrict__ inv_img, const double* __restrict__ inv_out,
+                                                        const float* __restrict__ img_lut, const float* __restrict__ xlut,
+                                                        const float* __restrict__ ylut, float* __restrict__ roi_img,
+                                                        float* __restrict__ roi_mask, float* __restrict__ roi_coord,
+                                                        int H, int W, int S, int R) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    int X, Y;
+    if (i < S * S) {
+        const int y = i / S, x = i - y * S;
+        const bool ok = warp_src(inv_img + b * 6, x, y, W, H, X, Y);
+        const unsigned char* px = frames + ((long)frame_idx[b] * H * W + (ok ? (long)Y * W + X : 0)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) roi_img[((long)b * 3 + c) * S * S + i] = img_lut[c * 256 + (ok ? px[c] : 0)];
+        roi_mask[(long)b * S * S + i] = (ok && masks[((long)mask_idx[b] * H + Y) * W + X]) ? 1.0f : 0.0f;
+    }
+    if (i < R * R) {
+        const int y = i / R, x = i - y * R;
+        const bool ok = warp_src(inv_out + b * 6, x, y, W, H, X, Y);
+        roi_coord[((long)b * 2 + 0) * R * R + i] = ok ? xlut[X] : 0.0f;
+        roi_coord[((long)b * 2 + 1) * R * R + i] = ok ? ylut[Y] : 0.0f;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------- eval post-processing
+__global__ __launch_bounds__(64) void pred_rt_kernel(const float* __restrict__ R, const float* __restrict__ t,
+                                                     const float* __restrict__ size, const float* __restrict__ scale,
+                                                     float* __restrict__ rt, float* __restrict__ ps, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float sc = scale ? scale[b] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rt[b * 16 + i * 4 + j] = R[b * 9 + i * 3 + j] * sc;
+        rt[b * 16 + i * 4 + 3] = t[b * 3 + i] * sc;
+    }
+    rt[b * 16 + 12] = 0.f; rt[b * 16 + 13] = 0.f; rt[b * 16 + 14] = 0.f; rt[b * 16 + 15] = 1.f;
+    const float x = size[b * 3], y = size[b * 3 + 1], z = size[b * 3 + 2];
+    const float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+    ps[b * 3] = x / n; ps[b * 3 + 1] = y / n; ps[b * 3 + 2] = z / n;
+}
+
 // ------------------------------------------------------------------------------------- bilinear x2
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
@@ -583,6 +640,29 @@ extern "C" int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int 
     if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, B, H, W, C);
     else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
     GP_LAUNCH_CHECK("gp_upsample_bilinear2x");
+}
+
+extern "C" int gp_crop_rois(const unsigned char* frames, const unsigned char* masks, const int* frame_idx, const int* mask_idx,
+                            const double* inv_img, const double* inv_out, const float* img_lut, const float* xlut,
+                            const float* ylut, float* roi_img, float* roi_mask, float* roi_coord_2d, int B, int F, int NM,
+                            int H, int W, int S, int R, void* stream) {
+    GP_REQUIRE(frames && masks && frame_idx && mask_idx && inv_img && inv_out && img_lut && xlut && ylut && roi_img && roi_mask && roi_coord_2d,
+               "gp_crop_rois: null pointer");
+    GP_REQUIRE(B > 0 && B <= 65535 && F > 0 && NM > 0 && H > 0 && W > 0 && S > 0 && R > 0 && R <= S, "gp_crop_rois: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 0.0, (double)B * (S * S * 4.0 * 4 + S * S * 4.0 + R * R * 8.0));
+    hipLaunchKernelGGL(crop_rois_kernel, dim3(cdiv(S * S, 256), B), dim3(256), 0, s, frames, masks, frame_idx, mask_idx, inv_img,
+                       inv_out, img_lut, xlut, ylut, roi_img, roi_mask, roi_coord_2d, H, W, S, R);
+    GP_LAUNCH_CHECK("gp_crop_rois");
+}
+
+extern "C" int gp_pred_rt(const float* R, const float* t, const float* size, const float* scale, float* pred_rt,
+                          float* pred_size, int B, void* stream) {
+    GP_REQUIRE(R && t && size && pred_rt && pred_size && B > 0, "gp_pred_rt: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 0.0, (double)B * 35 * 4);
+    hipLaunchKernelGGL(pred_rt_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, R, t, size, scale, pred_rt, pred_size, B);
+    GP_LAUNCH_CHECK("gp_pred_rt");
 }
 
 extern "C" int gp_deconv_col2im(const float* cols, void* out, int B, int H, int W, int C, int dtype, void* stream) {

@@ -198,6 +198,27 @@ int gp_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtyp
 /* torchvision Resize(out, NEAREST) on a square fp32 mask (B,1,S,S) -> (B,1,R,R) (PoseNet.py:170,180). */
 int gp_mask_resize_nearest(const float* mask, float* out, int B, int S, int R, void* stream);
 
+/* Crop pre-processing on the device: the four cv2.warpAffine(..., INTER_NEAREST) crops of
+ * evaluation/load_data_eval.py:262-288 (via tools/dataset_utils.py:101-114) for B detections in one launch.
+ *   frames  (F,H,W,3) uint8, masks (NM,H,W) uint8 (non-zero = 1.0), frame_idx / mask_idx: (B) int32
+ *   inv_img / inv_out: (B,6) float64 = the INVERTED 2x3 affine maps dst->src for the img_size (S) and out_res (R)
+ *       crops, exactly what cv::warpAffine computes before its fixed-point walk (host: givepose_amd/preprocess.py)
+ *   img_lut (3,256) fp32 = ((v/255 - mean[c]) / std[c]) evaluated in float64 like numpy, xlut (W) / ylut (H) fp32 =
+ *       the normalised pixel grid of get_2d_coord_np (tools/dataset_utils.py:8-30)
+ *   -> roi_img (B,3,S,S) fp32, roi_mask (B,1,S,S) fp32, roi_coord_2d (B,2,R,R) fp32; source pixel
+ *       X = (rint((M1*y + M2)*1024) + 512 + rint(M0*x*1024)) >> 10 (Y alike), constant-0 border (so a border pixel
+ *       of roi_img is the normalised value of 0, as in the reference). */
+int gp_crop_rois(const unsigned char* frames, const unsigned char* masks, const int* frame_idx, const int* mask_idx,
+                 const double* inv_img, const double* inv_out, const float* img_lut, const float* xlut, const float* ylut,
+                 float* roi_img, float* roi_mask, float* roi_coord_2d, int B, int F, int NM, int H, int W, int S, int R,
+                 void* stream);
+
+/* Evaluation post-processing (evaluation/evaluate.py:116-125): pred_RT (B,4,4) fp32 =
+ * [[R | t] * scale, 0 0 0 1] and pred_size (B,3) = size / max(||size||_2, 1e-12) (F.normalize).  R (B,9), t (B,3),
+ * size (B,3), scale (B) fp32 on the device; scale may be null (= 1). */
+int gp_pred_rt(const float* R, const float* t, const float* size, const float* scale, float* pred_rt, float* pred_size,
+               int B, void* stream);
+
 /* ---- hipGraph capture of a launch sequence (launch-bound inner loop -> one graph launch) */
 int gp_graph_begin(void* stream);
 int gp_graph_end(void* stream, void** graph_exec_out);
