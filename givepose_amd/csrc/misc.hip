@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
         a1 -= mean;
         const float rstd = rsqrtf(group_sum(a0 * a0 + a1 * a1, 64) * (1.0f / C0) + eps);
         T* o = out + (((long)b * Ho + ho) * Wo + wo0 + p) * C0 + lane * 2;
-        store_T(o, a0 * rstd * gw.x + gb.x);
-        store_T(o + 1, a1 * rstd * gw.y + gb.y);
+        const float o0 = a0 * rstd * gw.x + gb.x, o1 = a1 * rstd * gw.y + gb.y;
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<half2v*>(o) = half2v{(half_t)o0, (half_t)o1};   // one 4-byte store
+        else *reinterpret_cast<f32x2*>(o) = f32x2{o0, o1};
     }
 }
 

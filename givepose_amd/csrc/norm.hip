@@ -852,7 +852,10 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
         else launch_dw7_mfma<4, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
-    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && H % 8 == 0 && W % 8 == 0) {
+    // the LDS-tiled VALU kernel needs >= ~192 tiles of 8x8 pixels to fill the chip; below that (stage 3 at bs = 64: one
+    // tile per image, 64 workgroups) the strip kernel with 16 pixels per workgroup is 1.7x faster (scripts/dw_bench.py)
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && H % 8 == 0 && W % 8 == 0 && dbg != 7 &&
+        ((long)B * (H / 8) * (W / 8) >= 192 || dbg == 4)) {   // act code 104 forces it (tests)
         const int nslab = C / (16 * (16 / esz));
         bool done = true;
         if (dtype == GP_F16) {
