@@ -438,9 +438,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128>
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP p) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
+    static_assert(!PP || (WM * WN == 8 && (NS == 4 || NS == 5) && RB == 64 && !DB), "ping-pong schedule: 8 waves, 4/5-stage ring of 64-byte K steps");
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     // RB = bytes of K per LDS row and per K step: 128 (two MFMA k-groups per step) or 64 (one; half the stage
@@ -601,6 +602,71 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     };
 
     constexpr int G = XI + WI;
+    if constexpr (PP) {
+        // ---- Ping-pong schedule (8 waves = two groups of four, one wave of each group per SIMD).  Per K step a wave
+        // runs a LOAD phase [issue its 12 fragment reads of step t | issue the DMA of step t+LEAD | wait for its own
+        // DMA of step t+1 | barrier] and an MFMA phase [wait for the fragments | 32 MFMAs | barrier]; group 1 starts
+        // one barrier late, so on every SIMD one wave multiplies while its partner loads and the matrix pipe never
+        // waits for an LDS read, a DMA issue or a barrier.  Ring of NS stages, DMA lead LEAD = NS - 2 steps, counted vmcnt.
+        //   RAW: step t is read in interval 2t (group 0) / 2t+1 (group 1); every wave waited for its own DMA of step t
+        //        in its load phase of step t-1 (intervals 2t-2 / 2t-1), i.e. before barrier 2t.
+        //   WAR: the DMA of step t+LEAD overwrites the slot of step t-2 and is issued in interval 2t at the earliest;
+        //        the last reads of step t-2 (group 1, issued in interval 2t-3) were retired by the lgkmcnt(0) at the
+        //        head of interval 2t-2: two barriers earlier.
+        constexpr int LEAD = NS - 2;
+        const int grp = wave >> 2;
+        const int co = (fq ^ ((-(fr >> 2)) & 3)) << 4;
+        uint4 xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i)
+            if (i < p.nkt) stage(i, i);
+        // wait for step 0 (the load phase of step t waits for step t+1)
+        if constexpr (LEAD == 3) {
+            if (p.nkt >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            else if (p.nkt == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (p.nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (grp) __builtin_amdgcn_s_barrier();
+        int buf = 0, nbuf = LEAD;
+        for (int kt = 0; kt < p.nkt; ++kt) {
+            if (p.dbg != 2) {
+                const char* xs = smem + buf * STAGE + xfo;
+                const char* ws = smem + buf * STAGE + BM * RB + wfo;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 1024 + co);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 1024 + co);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + LEAD < p.nkt && (p.dbg != 1 || kt + LEAD < NS)) stage(nbuf, kt + LEAD);
+            // own DMA of step t+1 landed; steps t+2 .. t+LEAD stay in flight
+            if (LEAD == 3 && kt + 3 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+            else if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (p.dbg != 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();
+    } else
     if constexpr (DB && NS == 2) {
         // Software-pipelined schedule (2 LDS stages, 2 fragment register sets F0/F1), per K step t:
         //   read F1 <- (t, k-half 1) | MFMA(F0) | wait own LDS reads + own DMA(t+1), barrier |
@@ -766,15 +832,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     }
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128> void launch_big(GemmKP& p, hipStream_t s) {
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
+
+// A/B switch for bench runs on one device: GP_GEMM_PP=0 keeps the ping-pong kernel out of the automatic choice
+static bool pp_enabled() {
+    static const bool on = [] { const char* e = getenv("GP_GEMM_PP"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(d != nullptr, "gp_gemm: null descriptor");
@@ -830,18 +902,31 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          (d->epilogue >= GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
     // variant: 1 = 128x128 register-staged (+split-K), 2 = 256x128 LDS-DMA, 3 = 256x256 LDS-DMA, 0 = pick
-    int variant = d->variant % 10;
-    p.dbg = d->variant / 10;
+    int variant = d->variant % 100;
+    p.dbg = d->variant / 100;
     if (variant == 0) {
-        // measured per shape (scripts/gemm_bench.py): with the lean epilogue the 256x128 tile at two workgroups per CU
-        // (8) beats 256x256 (6) wherever that filled the chip (N % 256 == 0, >= 192 tiles of 256x256); otherwise
+        // measured per shape (scripts/gemm_bench.py): where 256x256 tiles fill the chip (N % 256 == 0, >= 192 tiles)
+        // the ping-pong kernel (10) for K >= 512 and the 256x128 tile at two workgroups per CU (8) for shorter K
+        // (its epilogues overlap the other workgroup's main loop); otherwise
         // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
-        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && tA >= 192) ? 8 : 7;
+        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && tA >= 192) ? ((d->K >= 512 && pp_enabled()) ? 10 : 8) : 7;
         else variant = 4;
     }
-    GP_REQUIRE(variant >= 1 && variant <= 9 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    GP_REQUIRE(variant >= 1 && variant <= 12 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    if (variant == 12) {   // as 10 with a 5-stage ring (all 160 KB of LDS), DMA lead 3
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 5, false, 64, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 10) {   // 256x256 ping-pong: 8 waves of 128x64, 64-byte K steps, 4-stage ring, one workgroup per CU
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 11) {   // 128x256 ping-pong: 8 waves of 64x64
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 4, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     if (variant == 8) {   // 256x128, 4 waves of 128x64, 64-byte K steps, 3-stage ring: two workgroups per CU, so the
                           // epilogue of one overlaps the main loop of the other (short-K, store-heavy shapes)
         if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);

@@ -64,6 +64,7 @@ struct Rec {
     hipEvent_t a, b;
     int cls;
     double flops, bytes;
+    const char* name;
 };
 bool g_timing = false;
 hipStream_t g_tstream = nullptr;
@@ -99,8 +100,9 @@ void gp_timing_before(hipStream_t s, int cls, double flops, double bytes) {
     g_open = true;
 }
 
-int gp_timing_after(const char*) {
+int gp_timing_after(const char* name) {
     if (g_open) {
+        g_cur.name = name;
         hipEventRecord(g_cur.b, g_tstream);
         g_recs.push_back(g_cur);
         g_open = false;
@@ -120,9 +122,14 @@ extern "C" int gp_timing_end(void) {
     g_timing = false;
     hipError_t e = hipStreamSynchronize(g_tstream);
     if (e != hipSuccess) return gp_fail(GP_ERR_RUNTIME, "timing sync: %s", hipGetErrorString(e));
+    // GP_TIMING_DUMP=<file>: one line per launch (sequence number, class, entry point, us, algorithmic FLOP / bytes)
+    const char* dump = getenv("GP_TIMING_DUMP");
+    FILE* df = dump ? fopen(dump, "w") : nullptr;
+    int seq = 0;
     for (auto& r : g_recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
+        if (df) fprintf(df, "%d %d %s %.2f %.0f %.0f\n", seq++, r.cls, r.name ? r.name : "?", ms * 1e3, r.flops, r.bytes);
         Acc& a = g_acc[r.cls];
         a.n++;
         a.ms += ms;
@@ -131,6 +138,7 @@ extern "C" int gp_timing_end(void) {
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
+    if (df) fclose(df);
     g_recs.clear();
     return GP_OK;
 }

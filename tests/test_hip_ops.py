@@ -100,7 +100,7 @@ def test_conv_implicit_gemm(dt, cfg):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_large_tile_variants(dt, variant):
     """256x128 / 256x256 LDS-DMA tiles: ragged M and N edges, every epilogue, ld strides, conv with padding."""
     o = ops()
@@ -126,6 +126,33 @@ def test_gemm_large_tile_variants(dt, variant):
         out = o.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to("cuda", dt),
                             w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", dt), k, k, s_, p_, variant=variant)
         assert rel_err(out, ref) < TOL[dt], cfg
+
+
+@pytest.mark.parametrize("variant", [10, 11, 12])
+def test_gemm_pingpong_bitwise_vs_plain_schedule(variant):
+    """Race screen for the ping-pong schedule (counted vmcnt, LDS ring re-use): every accumulator sees the same k
+    order as in the two-stage kernel, so the fp16 outputs must be bit-identical, over repeated launches."""
+    o = ops()
+    dt = torch.float16
+    for (M, N, K) in [(4096, 1024, 2048), (2048 + 128, 512 + 64, 64), (8192, 256, 192), (512, 512, 128)]:
+        x = rnd(M, K, seed=71).to("cuda", dt)
+        w = rnd(N, K, seed=72, scale=K ** -0.5).to("cuda", dt)
+        # aligned shapes: bias + GELU (both sides run the lean epilogue); ragged shapes: no bias, no activation (the
+        # edge tiles of the two tilings differ and the generic epilogue adds the bias after the sum, not before)
+        aligned = M % 256 == 0 and N % 256 == 0
+        b = rnd(N, seed=73).cuda() if aligned else None
+        epi = o.EPI_GELU if aligned else o.EPI_NONE
+        ref = torch.empty(M, N, dtype=dt, device="cuda")
+        o.gemm(x, w, ref, bias=b, epilogue=epi, variant=4)
+        for _ in range(5):
+            out = torch.zeros(M, N, dtype=dt, device="cuda")
+            o.gemm(x, w, out, bias=b, epilogue=epi, variant=variant)
+            assert torch.equal(out, ref), (M, N, K)
+    xc = rnd(8, 32, 32, 256, seed=74).to("cuda", dt)
+    wc = rnd(256, 9 * 256, seed=75, scale=0.02).to("cuda", dt)
+    ref = o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=4)
+    for _ in range(3):
+        assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant), ref)
 
 
 def test_gemm_rejects_bad_shapes():
