@@ -35,6 +35,8 @@ PROTOTYPES = {
     "gp_device_info": ([POINTER(c_int), c_char_p, c_int], c_int),
     "gp_dcnv3_forward": ([_P, _P, _P, _P] + [c_int] * 9 + [c_float] + [c_int] * 7 + [_P], c_int),
     "gp_gemm": ([POINTER(GemmDesc), _P], c_int),
+    "gp_convnext_mlp_pack_w2": ([_P, _P, c_int, _P], c_int),
+    "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
     "gp_dwconv_ln": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, c_long, c_int, _P], c_int),
     "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, c_int, _P], c_int),

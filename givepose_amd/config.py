@@ -26,6 +26,8 @@ class PoseNetConfig:
     # ConvNeXt-Base (timm convnext_base, network/backbone.py:36-46)
     convnext_dims: Tuple[int, ...] = (128, 256, 512, 1024)
     convnext_depths: Tuple[int, ...] = (3, 3, 27, 3)
+    # build-side switch (not a reference flag): fp16 stages with C in {128, 256} run fc1 -> GELU -> fc2 as one kernel
+    fuse_mlp: bool = True
 
     @property
     def feature_channel(self) -> int:

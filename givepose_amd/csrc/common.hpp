@@ -107,6 +107,32 @@ __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
     const f32x2 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
 }
+// the same polynomial on eight 2-vectors walked in lock step: eight independent dependency chains, so the packed FMAs
+// issue back to back instead of waiting out each other's latency (fused MLP kernel, csrc/mlp.hip)
+__device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) {
+    f32x2 xc[8], t[8], p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xc[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -4.4f, 4.4f);
+        xc[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -4.4f, 4.4f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = xc[i] * xc[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(f32x2{6.9778819482e-11f, 6.9778819482e-11f}, t[i], f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
+    constexpr float cf[7] = {3.4381198132e-07f, -9.3718131897e-06f, 1.6778340171e-04f, -2.1052074914e-03f,
+                             1.9270481587e-02f, -1.3212860816e-01f, 7.9751050727e-01f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{cf[k], cf[k]});
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 e = xc[i] * p[i];
+        const f32x2 hx = x[i] * 0.5f;
+        x[i] = __builtin_elementwise_fma(hx, e, hx);
+    }
+}
 __device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }
 
 template <typename T> __device__ __forceinline__ float gelu_for(float v) {

@@ -1,0 +1,281 @@
+// Fused ConvNeXt block MLP for gfx950 (fp16 storage):
+//
+//   out[m][c] = res[m][c] + gamma[c] * ( sum_h GELU( sum_k x[m][k] W1[h][k] + b1[h] ) * W2[c][h] + b2[c] )
+//
+// i.e. timm ConvNeXtBlock's  fc1 -> GELU -> fc2 -> gamma * . + shortcut  (network/backbone.py:36-46 builds it) in one
+// launch, for C = 128 / 256 (stages 0 / 1) where the 4C-wide hidden tensor (268 / 134 MB at 64 crops) otherwise makes
+// a round trip through HBM between the two GEMMs.  The hidden activations never leave the registers:
+//
+//   * a wave owns 32 rows (two MFMA m-tiles); its x rows are loaded once as MFMA B fragments (C/32 k-steps);
+//   * the hidden dimension is walked in chunks of 32 units.  GEMM1 (A = 32 rows of W1, B = x) leaves, per lane,
+//     h[m = fr][hn = nt*16 + fq*4 + j] for the two n-tiles nt of the chunk: after bias (accumulator init), GELU and
+//     the conversion to fp16 those 8 values ARE the B fragment of a 16x16x32 MFMA over the chunk, with k-slot
+//     fq*8 + nt*4 + j <-> hidden unit nt*16 + fq*4 + j.  The host stores W2 with its columns permuted the same way
+//     (gp_convnext_mlp_pack_w2), so GEMM2's A fragment is an ordinary 16-byte read;
+//   * W1 / W2 chunks (16 / 32 KB per step) stream through a 4-stage LDS ring by LDS-DMA (source-side XOR swizzle,
+//     conflict-free ds_read_b128), 3 steps ahead, one barrier per chunk; weights are L2 resident;
+//   * epilogue: gamma in the MFMA layout, fp16, transpose through a wave-private LDS slab, residual added with
+//     packed fp16 adds, whole 256/512-byte rows stored 16 B per lane (in place over the residual is allowed).
+//
+// Eight waves per workgroup (256 rows), two per SIMD: the GELU of one wave (VALU) runs under the MFMAs of the other.
+#include "common.hpp"
+
+namespace {
+
+struct MlpKP {
+    const half_t* X;      // (M, C) LayerNorm output
+    const half_t* W1;     // (4C, C)
+    const float* b1;      // (4C)
+    const half_t* W2p;    // (C, 4C), columns permuted per 32-block (see above)
+    const float* b2;      // (C)
+    const float* gamma;   // (C)
+    const half_t* res;    // (M, C)
+    half_t* out;          // (M, C)
+    int M;
+    int dbg;   // timing ablations (GP_MLP_DBG): 1 = no GELU, 2 = no in-loop DMA (wrong results)
+};
+
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
+    constexpr int HD = 4 * C, NCH = HD / 32, KS = C / 32, CT = C / 16, MT = 2;
+    constexpr int ROWB = C * 2;                        // bytes per W1 row
+    constexpr int W1B = 32 * ROWB, W2B = C * 64;       // bytes per chunk
+    constexpr int STAGE = W1B + W2B, NS = 4, LEAD = 3;
+    constexpr int I1 = W1B / 1024 / 8, I2 = W2B / 1024 / 8, G = I1 + I2;   // LDS-DMA instructions per wave and chunk
+    constexpr int CPR1 = ROWB / 16, RPI1 = 64 / CPR1;  // 16-byte chunks per W1 row, W1 rows per DMA instruction
+    constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
+    constexpr int RING = NS * STAGE, SMEM = (RING + HD * 4) > 8 * SLAB ? (RING + HD * 4) : 8 * SLAB;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long m0 = (long)blockIdx.x * 256 + wave * 32;
+
+    // ---- bias of the hidden layer -> LDS (read back per chunk as the accumulators' initial value)
+    float* b1s = reinterpret_cast<float*>(smem + RING);
+    for (int i = tid; i < HD / 4; i += 512) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+
+    // ---- this wave's x rows as B fragments: lane (fr, fq) holds x[m][ks*32 + fq*8 .. +8]
+    uint4 xf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[mt][ks] = *reinterpret_cast<const uint4*>(p.X + (m0 + mt * 16 + fr) * C + ks * 32 + fq * 8);
+
+    // ---- DMA sources.  W1 chunk image: [32 rows][ROWB], 16-byte chunk ^= row & 15; W2 chunk image: [C rows][64 B],
+    //      chunk ^= (-(row>>2)) & 3 inside each group of 16 rows (both involutions are repeated on the fragment reads)
+    const char* w1src[I1];
+    const char* w2src[I2];
+#pragma unroll
+    for (int i = 0; i < I1; ++i) {
+        const int r = (i * 8 + wave) * RPI1 + lane / CPR1, pc = lane % CPR1;
+        w1src[i] = reinterpret_cast<const char*>(p.W1 + (long)r * C + ((pc ^ (r & 15)) << 3));
+    }
+#pragma unroll
+    for (int i = 0; i < I2; ++i) {
+        const int lr = lane >> 2, r = (i * 8 + wave) * 16 + lr;
+        w2src[i] = reinterpret_cast<const char*>(p.W2p + (long)r * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3));
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    auto stage = [&](int buf, int ch) {
+        const unsigned s1 = lds0 + buf * STAGE + wave * 1024, s2 = s1 + W1B;
+#pragma unroll
+        for (int i = 0; i < I1; ++i) glds16(w1src[i] + (long)ch * W1B, s1 + i * 8192);
+#pragma unroll
+        for (int i = 0; i < I2; ++i) glds16(w2src[i] + (long)ch * 64, s2 + i * 8192);
+    };
+
+    f32x4 acc2[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + ct * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc2[ct][mt] = b;
+    }
+    __syncthreads();   // b1s visible; every compiler-visible global load above has been waited for before the DMA starts
+
+#pragma unroll
+    for (int i = 0; i < LEAD; ++i) stage(i, i);
+
+    const int w1fo = fr * ROWB, w2fo = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+    int buf = 0, nbuf = LEAD;
+    for (int ch = 0; ch < NCH; ++ch) {
+        // own DMA of chunk ch landed (chunks ch+1, ch+2 stay in flight), then the barrier publishes it and retires
+        // every wave's reads of chunk ch-1, whose slot the DMA of chunk ch+3 is about to overwrite
+        if (ch + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + LEAD < NCH && p.dbg != 2) stage(nbuf, ch + LEAD);
+        const char* s1 = smem + buf * STAGE + w1fo;
+        const char* s2 = smem + buf * STAGE + W1B + w2fo;
+
+        // ---- fragment reads of the whole chunk up front (hipcc otherwise re-uses ONE fragment register set and waits
+        //      lgkmcnt(0) in front of every MFMA pair); W2's land under GEMM1 and the GELU
+        constexpr int GK = KS > 4 ? 2 : KS;          // k-steps of W1 fragments resident at a time (register budget)
+        f32x4 acc1[2][MT];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + ch * 32 + nt * 16 + fq * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = b;
+        }
+        // ---- GEMM1: h[32 rows][32 hidden units of this chunk], bias as the initial value
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += GK) {
+            uint4 a1[GK][2];
+#pragma unroll
+            for (int ks = 0; ks < GK; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    a1[ks][nt] = *reinterpret_cast<const uint4*>(s1 + nt * 16 * ROWB + ((((k0 + ks) * 4 + fq) ^ fr) << 4));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < GK; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = mma16(a1[ks][nt], xf[mt][k0 + ks], acc1[nt][mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int GC = CT > 8 ? 4 : CT;          // W2 fragments resident at a time
+        uint4 a2[GC];
+#pragma unroll
+        for (int ct = 0; ct < GC; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + ct * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GELU on the 16 values of this lane, as 8 independent packed chains walked in lock step, then fp16:
+        //      the B fragments of GEMM2 (k-slot fq*8 + nt*4 + j)
+        f32x2 v[8];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                v[(mt * 2 + nt) * 2 + 0] = f32x2{acc1[nt][mt][0], acc1[nt][mt][1]};
+                v[(mt * 2 + nt) * 2 + 1] = f32x2{acc1[nt][mt][2], acc1[nt][mt][3]};
+            }
+        if (p.dbg == 1) {
+        } else if constexpr (C == 128) {
+            gelu_poly2_x8(v);
+        } else {   // C = 256 has no registers left for eight chains in flight
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gelu_poly2(v[i]);
+        }
+        uint4 hb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            half8 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e * 2 + 0] = (half_t)v[mt * 4 + e][0];
+                h[e * 2 + 1] = (half_t)v[mt * 4 + e][1];
+            }
+            hb[mt] = *reinterpret_cast<const uint4*>(&h);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GEMM2: out[32 rows][C] += h_chunk * W2p_chunk^T
+#pragma unroll
+        for (int c0 = 0; c0 < CT; c0 += GC) {
+            if (c0 > 0) {
+#pragma unroll
+                for (int ct = 0; ct < GC; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + (c0 + ct) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < GC; ++ct)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc2[c0 + ct][mt] = mma16(a2[ct], hb[mt], acc2[c0 + ct][mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
+    __syncthreads();   // every wave is done with the ring: the slabs overlay it
+
+    // ---- epilogue
+    constexpr int LPR = ROWB / 16, RPS = 64 / LPR, NIT = 32 / RPS;   // lanes per row, rows per store instruction
+    const int rr = lane / LPR, rc = lane % LPR;
+    half8 rres[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
+    char* slab = smem + wave * SLAB;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + ct * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc2[ct][mt] * g;
+            half4 o;
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+            *reinterpret_cast<half4*>(slab + (mt * 16 + fr) * PITCH + (ct * 4 + fq) * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        half8 v = *reinterpret_cast<const half8*>(slab + (i * RPS + rr) * PITCH + rc * 16);
+        v += rres[i];
+        *reinterpret_cast<half8*>(p.out + (m0 + i * RPS + rr) * C + rc * 8) = v;
+    }
+}
+
+// W2 (C, 4C) -> W2p: inside every block of 32 hidden units, k-slot s = fq*8 + nt*4 + j takes unit nt*16 + fq*4 + j
+__global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)C * HD) return;
+    const int c = (int)(i / HD), s = (int)(i - (long)c * HD);
+    const int blk = s >> 5, t = s & 31, fq = t >> 3, nt = (t >> 2) & 1, j = t & 3;
+    w2p[i] = w2[(long)c * HD + blk * 32 + nt * 16 + fq * 4 + j];
+}
+
+}  // namespace
+
+extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream) {
+    GP_REQUIRE(w2 && w2p && w2 != w2p, "gp_convnext_mlp_pack_w2: bad pointers");
+    GP_REQUIRE(C == 128 || C == 256, "gp_convnext_mlp_pack_w2: C=%d must be 128 or 256", C);
+    const long n = (long)C * 4 * C;
+    hipLaunchKernelGGL(mlp_pack_w2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(w2), reinterpret_cast<half_t*>(w2p), C, 4 * C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gp_fail(GP_ERR_LAUNCH, "gp_convnext_mlp_pack_w2: %s", hipGetErrorString(e));
+    return GP_OK;
+}
+
+extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
+                               const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream) {
+    GP_REQUIRE(dtype == GP_F16, "gp_convnext_mlp: fp16 storage only (fp32 runs fc1 / fc2 through gp_gemm)");
+    GP_REQUIRE(C == 128 || C == 256, "gp_convnext_mlp: C=%d must be 128 or 256", C);
+    GP_REQUIRE(x && w1 && b1 && w2p && b2 && gamma && residual && out, "gp_convnext_mlp: null operand");
+    GP_REQUIRE(M > 0 && M % 256 == 0, "gp_convnext_mlp: M=%ld must be a positive multiple of 256", M);
+    GP_REQUIRE((((size_t)x | (size_t)w1 | (size_t)w2p | (size_t)residual | (size_t)out | (size_t)b1 | (size_t)b2 | (size_t)gamma) & 15) == 0,
+               "gp_convnext_mlp: operands must be 16-byte aligned");
+    GP_REQUIRE(x != out, "gp_convnext_mlp: x and out must not alias (out may alias residual)");
+    MlpKP p;
+    p.X = reinterpret_cast<const half_t*>(x); p.W1 = reinterpret_cast<const half_t*>(w1); p.b1 = b1;
+    p.W2p = reinterpret_cast<const half_t*>(w2p); p.b2 = b2; p.gamma = gamma;
+    p.res = reinterpret_cast<const half_t*>(residual); p.out = reinterpret_cast<half_t*>(out); p.M = (int)M;
+    { const char* e = getenv("GP_MLP_DBG"); p.dbg = e ? atoi(e) : 0; }
+    hipStream_t s = (hipStream_t)stream;
+    const double flops = 2.0 * 2.0 * (double)M * C * 4 * C;
+    const double bytes = 3.0 * M * C * 2 + 2.0 * 4 * C * C * 2;
+    gp_timing_before(s, GP_KC_GEMM, flops, bytes);
+    if (C == 128) hipLaunchKernelGGL(convnext_mlp_kernel<128>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(convnext_mlp_kernel<256>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
+    GP_LAUNCH_CHECK("gp_convnext_mlp");
+}

@@ -130,6 +130,8 @@ class PoseNet(nn.Module):
                 W[q + "fc1_w"], W[q + "fc1_b"] = lowp(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
                 W[q + "fc2_w"], W[q + "fc2_b"] = lowp(g(p + "mlp.fc2.weight")), f32(g(p + "mlp.fc2.bias"))
                 W[q + "gamma"] = f32(g(p + "gamma"))
+                if T == torch.float16 and d in (128, 256) and cfg.fuse_mlp:   # fused fc1->GELU->fc2 (csrc/mlp.hip)
+                    W[q + "fc2_wp"] = ops.convnext_mlp_pack_w2(W[q + "fc2_w"])
         for head in ("xyz_nocs_head", "xyz_deform_head"):
             h = lambda k: sd[f"{head}.{k}"]
             W[head + ".deconv_w"] = lowp(h("features.0.weight").permute(2, 3, 1, 0).reshape(9 * 256, -1))
@@ -325,6 +327,10 @@ class PoseNet(nn.Module):
             for b in range(n):
                 q = f"s{s}b{b}."
                 t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7)
+                if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0:
+                    ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
+                                     W[q + "gamma"], x2d, x2d)
+                    continue
                 ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU)
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
                          gamma=W[q + "gamma"], residual=x2d)

@@ -100,6 +100,17 @@ typedef struct gp_gemm_desc {
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 
+/* Fused ConvNeXt block MLP (fp16 storage, C = 128 or 256): one launch for
+ *   out = residual + gamma * ( fc2( GELU( fc1(x) ) ) )
+ * i.e. timm ConvNeXtBlock.forward's `mlp` + layer scale + shortcut (built by network/backbone.py:36-46); replaces the
+ * gp_gemm(GELU) -> gp_gemm(SCALE_RES) pair for the stages whose 4C-wide hidden tensor would otherwise round-trip HBM.
+ *   x (M,C) = LayerNorm output, w1 (4C,C), b1 (4C) fp32, b2/gamma (C) fp32, residual/out (M,C) (out may alias
+ *   residual, not x); w2p = fc2.weight (C,4C) re-ordered by gp_convnext_mlp_pack_w2 (k-slot order of the MFMA B
+ *   fragment that the GELU output forms in registers).  M % 256 == 0; all pointers 16-byte aligned. */
+int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream);
+int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
+                    const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream);
+
 /* ConvNeXt stem: conv4x4 s4 (3->C0, bias) + LayerNorm over channels (eps).  img is the
  * reference's NCHW fp32 `roi_img` (network/PoseNet.py:174); out is (B,H/4,W/4,C0) channels-last.
  * w is (48, C0) fp32 tap-major, k = c*16 + kh*4 + kw (the checkpoint's (C0,3,4,4) transposed by the host).

@@ -155,6 +155,34 @@ def test_gemm_pingpong_bitwise_vs_plain_schedule(variant):
         assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant), ref)
 
 
+@pytest.mark.parametrize("C", [128, 256])
+def test_convnext_mlp_fused(C):
+    """Fused fc1 -> GELU -> fc2 -> gamma * . + shortcut against the fp32 formula (hidden rounded to fp16 like the
+    two-GEMM path) and against the two-GEMM HIP path itself; in place over the residual."""
+    o = ops()
+    dt = torch.float16
+    M, HD = 512, 4 * C
+    x, res = q(rnd(M, C, seed=81), dt), q(rnd(M, C, seed=82), dt)
+    w1, b1 = q(rnd(HD, C, seed=83, scale=C ** -0.5), dt), rnd(HD, seed=84)
+    w2, b2 = q(rnd(C, HD, seed=85, scale=HD ** -0.5), dt), rnd(C, seed=86)
+    gamma = rnd(C, seed=87)
+    hid = q(F.gelu(x @ w1.t() + b1), dt)
+    ref = res + gamma * (hid @ w2.t() + b2)
+    dev = lambda t, d=None: t.to("cuda", d) if d else t.cuda()
+    w2p = o.convnext_mlp_pack_w2(dev(w2, dt))
+    out = dev(res, dt).clone()
+    o.convnext_mlp(dev(x, dt), dev(w1, dt), dev(b1), w2p, dev(b2), dev(gamma), out, out)
+    assert rel_err(out, ref) < 2e-3
+    h2 = torch.empty(M, HD, dtype=dt, device="cuda")
+    out2 = dev(res, dt).clone()
+    o.gemm(dev(x, dt), dev(w1, dt), h2, bias=dev(b1), epilogue=o.EPI_GELU)
+    o.gemm(h2, dev(w2, dt), out2, bias=dev(b2), epilogue=o.EPI_SCALE_RES, gamma=dev(gamma), residual=out2)
+    assert rel_err(out, out2.float().cpu()) < 1e-3
+    from givepose_amd._lib import GivePoseHipError
+    with pytest.raises(GivePoseHipError):
+        o.convnext_mlp(dev(x, dt)[:100], dev(w1, dt), dev(b1), w2p, dev(b2), dev(gamma), out[:100], out[:100])
+
+
 def test_gemm_rejects_bad_shapes():
     o = ops()
     from givepose_amd._lib import GivePoseHipError
