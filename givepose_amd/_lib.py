@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgivepose_hip.so")
 
 GP_F32, GP_F16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
-EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
 KC_GEMM, KC_DCNV3, KC_DWCONV_LN, KC_NORM, KC_ELEMENTWISE, KC_SMALL, KC_COUNT = 0, 1, 2, 3, 4, 5, 6
 KC_NAMES = ["gemm", "dcnv3", "dwconv_ln", "norm", "elementwise", "small"]
 
@@ -24,7 +24,8 @@ class GemmDesc(Structure):
                 ("epilogue", c_int), ("out_f32", c_int), ("splitk", c_int),
                 ("B", c_int), ("H", c_int), ("Win", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
-                ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int)]
+                ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int),
+                ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)
@@ -39,6 +40,7 @@ PROTOTYPES = {
     "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
     "gp_dwconv_ln": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, c_long, c_int, _P], c_int),
+    "gp_dwconv7_raw_stats": ([_P] * 5 + [c_int] * 5 + [_P], c_int),
     "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, c_int, _P], c_int),
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),

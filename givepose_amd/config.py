@@ -28,6 +28,10 @@ class PoseNetConfig:
     convnext_depths: Tuple[int, ...] = (3, 3, 27, 3)
     # build-side switch (not a reference flag): fp16 stages with C in {128, 256} run fc1 -> GELU -> fc2 as one kernel
     fuse_mlp: bool = True
+    # build-side switch: fp16 stage with C = 512 runs the depth-wise conv one workgroup per 128-channel slab and applies
+    # the block's LayerNorm in fc1's GEMM epilogue (algebraically identical: LN is affine per row).  Measured on MI355X
+    # (bs 64): depth-wise 25.2 -> 22.9 us but fc1 52 -> 58 us per block, a net loss, hence off by default.
+    defer_ln: bool = False
 
     @property
     def feature_channel(self) -> int:

@@ -34,6 +34,10 @@ struct GemmKP {
     int tiles_m, tiles_n, nkt, kt_per_split, splitk;
     float* gn_partial;  // fused GroupNorm statistics (large-tile kernels): (B, HW/64, G, 2) chunk sums, or null
     int gn_cpg, gn_hw;
+    const float* ln_stats;   // GP_EPI_LNFOLD_GELU: (M, 2, ln_nsl) partial row moments, ln_s (N) column sums of W
+    const float* ln_s;
+    int ln_nsl;
+    float ln_eps;
     int dbg;  // timing-only ablations of the large-tile kernel: 1 = no in-loop DMA, 2 = no MFMA/LDS reads (wrong results)
 };
 
@@ -364,6 +368,34 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
             for (int i = 0; i < 8; ++i)
                 rres[h][i] = *reinterpret_cast<const half8*>(R + (long)(mb + h * 64 + i * 8 + rr) * p.ldres + nb + rc * 8);
     }
+    // LayerNorm folded into the epilogue: v = rstd[m] * acc + (bias[n] - rstd[m] * mean[m] * colsum[n])
+    constexpr bool LNF = EPI == GP_EPI_LNFOLD_GELU;
+    f32x4 lc4[LNF ? NT : 1], ls4[LNF ? NT : 1];
+    float lr[LNF ? MT : 1], lmr[LNF ? MT : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nb + nt * 16 + fq * 4;
+            lc4[nt] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            ls4[nt] = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+        }
+        const float invK = 1.0f / p.K;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* st = p.ln_stats + (long)(mb + mt * 16 + fr) * 2 * p.ln_nsl;
+            float su = 0.f, sq = 0.f;
+            if (p.ln_nsl == 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(st), b = *reinterpret_cast<const f32x4*>(st + 4);
+                su = (a[0] + a[1]) + (a[2] + a[3]);
+                sq = (b[0] + b[1]) + (b[2] + b[3]);
+            } else {
+                for (int i = 0; i < p.ln_nsl; ++i) { su += st[i]; sq += st[p.ln_nsl + i]; }
+            }
+            const float mu = su * invK;
+            lr[mt] = __builtin_amdgcn_rsqf(fmaxf(sq * invK - mu * mu, 0.f) + p.ln_eps);
+            lmr[mt] = -mu * lr[mt];
+        }
+    }
     half_t* C = reinterpret_cast<half_t*>(p.C);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -375,7 +407,12 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x4 v = acc[nt][h * 4 + ml];
-                if constexpr (EPI == GP_EPI_GELU) {
+                if constexpr (LNF) {
+                    const float r = lr[h * 4 + ml], mr = lmr[h * 4 + ml];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(r, v[j], fmaf(mr, ls4[nt][j], lc4[nt][j]));
+                }
+                if constexpr (EPI == GP_EPI_GELU || LNF) {
                     const f32x2 lo = gelu_poly2(f32x2{v[0], v[1]}), hi = gelu_poly2(f32x2{v[2], v[3]});
                     v = f32x4{lo[0], lo[1], hi[0], hi[1]};
                 } else if constexpr (EPI == GP_EPI_RELU) {
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lean && p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * NT * 16 + a * 16 + (lane >> 4) * 4);
+        if (lean && p.bias && p.epi != GP_EPI_LNFOLD_GELU) init = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * NT * 16 + a * 16 + (lane >> 4) * 4);
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
@@ -752,6 +789,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 case GP_EPI_LRELU: epilogue_lean<MT, NT, GP_EPI_LRELU>(p, acc, slab, mb, nb, lane); break;
                 case GP_EPI_SCALE_RES: epilogue_lean<MT, NT, GP_EPI_SCALE_RES>(p, acc, slab, mb, nb, lane); break;
                 case GP_EPI_RES_RELU: epilogue_lean<MT, NT, GP_EPI_RES_RELU>(p, acc, slab, mb, nb, lane); break;
+                case GP_EPI_LNFOLD_GELU: epilogue_lean<MT, NT, GP_EPI_LNFOLD_GELU>(p, acc, slab, mb, nb, lane); break;
                 default: epilogue_lean<MT, NT, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
             }
             return;
@@ -858,7 +896,17 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(d->N % 4 == 0, "gp_gemm: N=%d must be a multiple of 4", d->N);
     GP_REQUIRE(d->K % KPT == 0, "gp_gemm: K=%d must be a multiple of %d", d->K, KPT);
     GP_REQUIRE(d->ldc % 4 == 0 && d->ldc >= d->N, "gp_gemm: ldc=%d invalid", d->ldc);
-    GP_REQUIRE(d->epilogue >= GP_EPI_NONE && d->epilogue <= GP_EPI_RES_RELU, "gp_gemm: bad epilogue");
+    GP_REQUIRE(d->epilogue >= GP_EPI_NONE && d->epilogue <= GP_EPI_LNFOLD_GELU, "gp_gemm: bad epilogue");
+    if (d->epilogue == GP_EPI_LNFOLD_GELU) {   // lean epilogue of the large-tile kernels only (every tile interior)
+        GP_REQUIRE(d->dtype == GP_F16 && !d->out_f32 && d->splitk <= 1 && !d->gn_partial && d->KH == 0,
+                   "gp_gemm: LNFOLD_GELU needs a plain fp16 GEMM without split-K / fused GroupNorm");
+        GP_REQUIRE(d->bias && d->ln_stats && d->ln_colsum && d->ln_nslab > 0, "gp_gemm: LNFOLD_GELU needs bias, ln_stats, ln_colsum");
+        GP_REQUIRE(d->M % 256 == 0 && d->N % 256 == 0 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 &&
+                   ((size_t)d->ln_stats & 15) == 0 && ((size_t)d->ln_colsum & 15) == 0 && ((size_t)d->bias & 15) == 0,
+                   "gp_gemm: LNFOLD_GELU needs M %% 256 == 0, N %% 256 == 0 and 16-byte aligned operands");
+        GP_REQUIRE(d->variant % 100 == 0 || d->variant % 100 == 8 || d->variant % 100 == 10 || d->variant % 100 == 12,
+                   "gp_gemm: LNFOLD_GELU runs on variants 8 / 10 / 12");
+    }
     if (d->epilogue == GP_EPI_SCALE_RES) GP_REQUIRE(d->gamma != nullptr, "gp_gemm: SCALE_RES needs gamma");
     if (d->epilogue == GP_EPI_SCALE_RES || d->epilogue == GP_EPI_RES_RELU)
         GP_REQUIRE(d->residual && d->ldres % 4 == 0 && d->ldres >= d->N, "gp_gemm: epilogue needs a residual");
@@ -867,6 +915,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     p.X = d->X; p.W = d->W; p.bias = d->bias; p.gamma = d->gamma; p.res = d->residual; p.C = d->C; p.ws = d->workspace;
     p.M = d->M; p.N = d->N; p.K = d->K; p.ldx = d->ldx; p.ldc = d->ldc; p.ldres = d->ldres;
     p.epi = d->epilogue; p.out_f32 = d->out_f32;
+    p.ln_stats = d->ln_stats; p.ln_s = d->ln_colsum; p.ln_nsl = d->ln_nslab; p.ln_eps = d->ln_eps;
     if (d->gn_partial) {
         GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
                    "gp_gemm: fused GroupNorm needs 4 or 8 channels per group");
@@ -911,7 +960,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
-        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && tA >= 192) ? ((d->K >= 512 && pp_enabled()) ? 10 : 8) : 7;
+        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && (tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU)) ? ((d->K >= 512 && pp_enabled()) ? 10 : 8) : 7;
         else variant = 4;
     }
     GP_REQUIRE(variant >= 1 && variant <= 12 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);

@@ -316,12 +316,19 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
 // 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) on 16 different slots for all 7 shifts.  A wave owns one 16-channel group per 128-channel slab and keeps the
 // 28 A fragments (4 row pairs x 7 kw) in registers; a B fragment (rows r, r+1) is shared by the output rows t and
 // t+2 (tap pairs kp and kp-1).  Output tile 16 x 4 pixels, slabs double-buffered by LDS-DMA as above.
-template <int NSLAB, int NBUF>
+// RAW = true: one workgroup per (tile, 128-channel slab) (blockIdx.y = slab), no LayerNorm: y gets the conv + bias
+// output rounded to fp16 and `stats` (pixel, {sum, sum of squares}, slab) the per-pixel partial moments of those
+// ROUNDED values over the slab's channels; the LayerNorm is applied by the consuming GEMM's epilogue
+// (GP_EPI_LNFOLD_GELU).  Removes the serial slab chain of a workgroup and the all-channel reduction.
+template <int NSLAB, int NBUF, bool RAW = false>
 __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ lnw,
                                                               const float* __restrict__ lnb, half_t* __restrict__ y,
-                                                              int H, int W, int C, float eps, int dbg) {
+                                                              int H, int W, int C, float eps, int dbg,
+                                                              float* __restrict__ stats = nullptr) {
+    static_assert(!RAW || (NSLAB == 1 && NBUF == 1), "raw mode: one slab per workgroup");
+    const int slab0 = RAW ? (int)blockIdx.y : 0;
     constexpr int TW = 16, TH = 4, R = 3, IW = TW + 6, IH = TH + 6, NPX = IW * IH;
     constexpr int IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
     constexpr int BUF = (IN_INSTR + W_INSTR) * 1024;   // halo tile directly followed by the taps (see row 10 below)
@@ -352,12 +359,12 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
             const int ls = ps ^ ((ix & 7) << 1);
             const half_t* src = zero;
             if (px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                src = xb + ((long)gy * W + gx) * C + s * 128 + ls * 8;
+                src = xb + ((long)gy * W + gx) * C + (slab0 + s) * 128 + ls * 8;
             glds16_n(src, base + ins * 1024);
         }
         for (int ins = wave; ins < W_INSTR; ins += 8) {
             const int i = ins * 64 + lane, tap = i >> 4, sl = i & 15;
-            const half_t* src = tap < 49 ? wt + (long)tap * C + s * 128 + sl * 8 : zero;
+            const half_t* src = tap < 49 ? wt + (long)tap * C + (slab0 + s) * 128 + sl * 8 : zero;
             glds16_n(src, base + (IN_INSTR + ins) * 1024);
         }
     };
@@ -456,11 +463,52 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     const int cq = wave * 16 + q * 4;
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
-        const float4 bv = *reinterpret_cast<const float4*>(par_s + s * 128 + cq);
+        const float4 bv = *reinterpret_cast<const float4*>(par_s + (slab0 + s) * 128 + cq);
 #pragma unroll
         for (int t = 0; t < TH; ++t) {
             acc[s][t][0] += bv.x; acc[s][t][1] += bv.y; acc[s][t][2] += bv.z; acc[s][t][3] += bv.w;
         }
+    }
+    if constexpr (RAW) {
+        float* red2_s = stat_s + 64;                 // [8 waves][64 px] sums of squares
+        half4 o[TH];
+#pragma unroll
+        for (int t = 0; t < TH; ++t) {
+            float a = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[t][e] = (_Float16)acc[0][t][e];
+                const float f = (float)o[t][e];
+                a += f;
+                a2 += f * f;
+            }
+            a += __shfl_xor(a, 16); a2 += __shfl_xor(a2, 16);
+            a += __shfl_xor(a, 32); a2 += __shfl_xor(a2, 32);
+            if (q == 0) { red_s[wave * 64 + t * 16 + m] = a; red2_s[wave * 64 + t * 16 + m] = a2; }
+        }
+        __syncthreads();   // also: every wave is done reading the halo tile, which the output tile overlays
+        const int nsl = C >> 7;
+        if (tid < 128) {
+            const int which = tid >> 6, px = tid & 63;
+            const float* r = which ? red2_s : red_s;
+            float a = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) a += r[w8 * 64 + px];
+            const long pixel = ((long)b * H + h0 + (px >> 4)) * W + w0 + (px & 15);
+            stats[(pixel * 2 + which) * nsl + slab0] = a;
+        }
+        char* out_r = dsm;
+        const int chunk = wave * 2 + (q >> 1);
+#pragma unroll
+        for (int t = 0; t < TH; ++t)
+            *reinterpret_cast<half4*>(out_r + (t * 16 + m) * 256 + ((chunk ^ m) << 4) + (q & 1) * 8) = o[t];
+        __syncthreads();
+        for (int i = tid; i < 64 * 16; i += 512) {
+            const int px = i >> 4, c = i & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(out_r + px * 256 + ((c ^ (px & 15)) << 4));
+            *reinterpret_cast<uint4*>(y + (((long)b * H + h0 + (px >> 4)) * W + w0 + (px & 15)) * C + slab0 * 128 + c * 8) = v;
+        }
+        return;
     }
     const float invC = 1.0f / C;
     float mean[TH], rstd[TH];
@@ -535,6 +583,19 @@ void launch_dw7_mfma(const void* x, const void* wt, const float* bias, const flo
     }
     hipLaunchKernelGGL((dwconv7_ln_mfma_kernel<NSLAB, NBUF>), dim3(B * (H / 4) * (W / 16)), dim3(512), LDS, s, (const half_t*)x,
                        (const half_t*)wt, bias, lnw, lnb, (half_t*)y, H, W, C, eps, dbg);
+}
+
+void launch_dw7_raw(const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H, int W, int C,
+                    hipStream_t s) {
+    constexpr int NPX = 22 * 10, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
+    const int LDS = (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024 + 17 * 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_mfma_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dwconv7_ln_mfma_kernel<1, 1, true>), dim3(B * (H / 4) * (W / 16), C / 128), dim3(512), LDS, s, (const half_t*)x,
+                       (const half_t*)wt, bias, bias, bias, (half_t*)y, H, W, C, 0.f, 0, stats);
 }
 
 // ---------------------------------------------------------------------------- row LayerNorm
@@ -879,6 +940,19 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     else { if (KS == 7) GP_DW(float, 7); else GP_DW(float, 3); }
 #undef GP_DW
     GP_LAUNCH_CHECK("gp_dwconv_ln");
+}
+
+extern "C" int gp_dwconv7_raw_stats(const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,
+                                    int W, int C, int dtype, void* stream) {
+    GP_REQUIRE(x && wt && bias && y && stats, "gp_dwconv7_raw_stats: null pointer");
+    GP_REQUIRE(dtype == GP_F16, "gp_dwconv7_raw_stats: fp16 storage only");
+    GP_REQUIRE(C % 128 == 0 && C >= 128 && C <= 1024, "gp_dwconv7_raw_stats: C=%d must be a multiple of 128 (<= 1024)", C);
+    GP_REQUIRE(B > 0 && H % 4 == 0 && W % 16 == 0, "gp_dwconv7_raw_stats: H=%d %% 4, W=%d %% 16 required", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    const double px = (double)B * H * W;
+    gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * px * C * 49, px * C * 2 * 2);
+    launch_dw7_raw(x, wt, bias, y, stats, B, H, W, C, s);
+    GP_LAUNCH_CHECK("gp_dwconv7_raw_stats");
 }
 
 extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,

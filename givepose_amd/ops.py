@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_RELU, EPI_RES_RELU,
+from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LNFOLD_GELU, EPI_LRELU, EPI_NONE, EPI_RELU, EPI_RES_RELU,
                    EPI_SCALE_RES, GP_F16, GP_F32, GemmDesc, check)
 
 __all__ = ["dtype_code", "gemm", "conv2d_nhwc", "dcnv3_forward", "dcnv3_forward_into", "convnext_stem", "dwconv_ln",
@@ -74,7 +74,7 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None, variant=0, gn=None):
+         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
     dt = x.dtype
@@ -102,7 +102,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz) if (variant in (0, 1) and gn is None) else 1
+        splitk = auto_splitk(M, N, K, esz) if (variant in (0, 1) and gn is None and ln is None) else 1
     d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None
@@ -112,6 +112,8 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
+    if ln is not None:       # (row moments (M,2,nslab), column sums of w, nslab, eps): EPI_LNFOLD_GELU
+        d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2], ln[3]
     if gn is not None:       # (partial buffer, groups, pixels per image): fused GroupNorm statistics of the output
         d.gn_partial, d.gn_groups, d.gn_hw = gn[0].data_ptr(), gn[1], gn[2]
     check(_L().gp_gemm(ctypes.byref(d), _stream()), "gp_gemm")
@@ -198,6 +200,14 @@ def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels
     n = B * H * W_ if n_pixels is None else n_pixels
     check(_L().gp_dwconv_ln(_ptr(_contig(x, "x")), _ptr(wt), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, C, KS,
                             eps, act, n, dtype_code(x.dtype), _stream()), "gp_dwconv_ln")
+    return out
+
+
+def dwconv7_raw_stats(x, wt, bias, out, stats):
+    """Depth-wise 7x7 + bias only; per-pixel slab moments of the rounded output -> stats (pixels, 2, C/128) fp32."""
+    B, H, W_, C = x.shape
+    check(_L().gp_dwconv7_raw_stats(_ptr(_contig(x, "x")), _ptr(wt), _ptr(bias), _ptr(out), _ptr(stats), B, H, W_, C,
+                                    dtype_code(x.dtype), _stream()), "gp_dwconv7_raw_stats")
     return out
 
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops, synth
-from ._lib import (ACT_GELU, ACT_RELU, EPI_GELU, EPI_LRELU, EPI_NONE, EPI_SCALE_RES)
+from ._lib import (ACT_GELU, ACT_RELU, EPI_GELU, EPI_LNFOLD_GELU, EPI_LRELU, EPI_NONE, EPI_SCALE_RES)
 from .config import PoseNetConfig
 
 
@@ -132,6 +132,11 @@ class PoseNet(nn.Module):
                 W[q + "gamma"] = f32(g(p + "gamma"))
                 if T == torch.float16 and d in (128, 256) and cfg.fuse_mlp:   # fused fc1->GELU->fc2 (csrc/mlp.hip)
                     W[q + "fc2_wp"] = ops.convnext_mlp_pack_w2(W[q + "fc2_w"])
+                if T == torch.float16 and d == 512 and cfg.defer_ln:   # LayerNorm folded into fc1's epilogue
+                    w1, lw, lb = g(p + "mlp.fc1.weight"), g(p + "norm.weight"), g(p + "norm.bias")
+                    W[q + "fc1_wg"] = lowp(w1 * lw[None, :])
+                    W[q + "fc1_cs"] = f32(W[q + "fc1_wg"].float().sum(1))          # column sums of the ROUNDED weights
+                    W[q + "fc1_cb"] = f32(w1 @ lb + g(p + "mlp.fc1.bias"))
         for head in ("xyz_nocs_head", "xyz_deform_head"):
             h = lambda k: sd[f"{head}.{k}"]
             W[head + ".deconv_w"] = lowp(h("features.0.weight").permute(2, 3, 1, 0).reshape(9 * 256, -1))
@@ -229,6 +234,8 @@ class PoseNet(nn.Module):
             buf[f"x{s}"] = e(B, h, h, d)
             buf[f"t{s}"] = e(B, h, h, d)
             buf[f"h{s}"] = e(B * h * h, 4 * d)
+            if d == 512:
+                buf["ln_stats"] = f(B * h * h, 2, d // 128)
             if s > 0:
                 buf[f"dsn{s}"] = e(B, h * 2, h * 2, dims[s - 1])
         # heads
@@ -326,6 +333,13 @@ class PoseNet(nn.Module):
             x2d = x.view(-1, d)
             for b in range(n):
                 q = f"s{s}b{b}."
+                if (q + "fc1_wg") in W and x2d.shape[0] % 256 == 0 and x.shape[1] % 4 == 0 and x.shape[2] % 16 == 0:
+                    t = ops.dwconv7_raw_stats(x, W[q + "dw_w"], W[q + "dw_b"], buf[f"t{s}"], buf["ln_stats"])
+                    ops.gemm(t.view(-1, d), W[q + "fc1_wg"], buf[f"h{s}"], bias=W[q + "fc1_cb"], epilogue=EPI_LNFOLD_GELU,
+                             ln=(buf["ln_stats"], W[q + "fc1_cs"], d // 128, 1e-6))
+                    ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
+                             gamma=W[q + "gamma"], residual=x2d)
+                    continue
                 t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7)
                 if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0:
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],

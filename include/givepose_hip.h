@@ -33,7 +33,12 @@ enum gp_epilogue {
     GP_EPI_RELU = 2,      /* out = max(v, 0)                                */
     GP_EPI_LRELU = 3,     /* out = v > 0 ? v : 0.1 v                        */
     GP_EPI_SCALE_RES = 4, /* out = residual + gamma[n] * v  (ConvNeXt block) */
-    GP_EPI_RES_RELU = 5   /* out = max(residual + v, 0)    (ResNet BasicBlock, network/resnet.py:49-52) */
+    GP_EPI_RES_RELU = 5,  /* out = max(residual + v, 0)    (ResNet BasicBlock, network/resnet.py:49-52) */
+    /* LayerNorm of the X rows folded into the epilogue (fp16, large-tile kernels): with X = un-normalised rows,
+     * W = fc.weight * ln.weight[k], ln_colsum[n] = sum_k W[n][k], bias[n] = fc.weight @ ln.bias + fc.bias and per-row
+     * (mean, rstd) from ln_stats (gp_dwconv7_raw_stats):  out = gelu( rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n] ),
+     * which equals gelu(fc(LayerNorm(x))) -- ConvNeXt block norm -> mlp.fc1 -> act */
+    GP_EPI_LNFOLD_GELU = 6
 };
 
 const char* gp_last_error(void);
@@ -97,6 +102,12 @@ typedef struct gp_gemm_desc {
     float* gn_partial;
     int gn_groups, gn_hw;
     int variant; /* 0 = choose by shape; 1 = 128x128 tile (split-K capable), 2 = 256x128, 3 = 256x256 LDS-DMA tiles */
+    /* GP_EPI_LNFOLD_GELU only: ln_stats (M, 2, ln_nslab) fp32 partial (sum, sum of squares) of each X row over
+     * ln_nslab channel slabs; ln_colsum (N) fp32; ln_eps.  Requires M % 256 == 0, N % 256 == 0, fp16 output. */
+    const float* ln_stats;
+    const float* ln_colsum;
+    int ln_nslab;
+    float ln_eps;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 
@@ -125,6 +136,13 @@ int gp_convnext_stem(const float* img, const float* w, const float* b, const flo
 int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b,
                  void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
                  void* stream);
+
+/* ConvNeXt block front half with the LayerNorm deferred to the consuming GEMM (GP_EPI_LNFOLD_GELU): depth-wise 7x7
+ * (pad 3, bias) only; y = conv output rounded to fp16, stats (B*H*W, 2, C/128) fp32 = per pixel the (sum, sum of
+ * squares) of those rounded values over each 128-channel slab.  One workgroup per (16x4 pixel tile, slab), so the
+ * launch has C/128 times the workgroups of gp_dwconv_ln.  fp16, C % 128 == 0, H % 4 == 0, W % 16 == 0. */
+int gp_dwconv7_raw_stats(const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H, int W,
+                         int C, int dtype, void* stream);
 
 /* row LayerNorm over C (ConvNeXt downsample LayerNorm2d, ViT-block norms); y row stride ldy (0 = C). */
 int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps, int ldy,

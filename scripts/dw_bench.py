@@ -8,7 +8,7 @@ for (C, H) in ((128, 64), (256, 32), (512, 16), (1024, 8)):
     w = torch.randn(49, C, device="cuda").half()
     b = torch.randn(C, device="cuda"); lw = torch.randn(C, device="cuda"); lb = torch.randn(C, device="cuda")
     y = torch.empty_like(x)
-    for act in (0, 104, 107):
+    for act in [int(a) for a in os.environ.get("MODES", "0,104,107").split(",")]:
         f = lambda: ops.dwconv_ln(x, w, b, lw, lb, y, 7, act=act)
         for _ in range(3): f()
         torch.cuda.synchronize()

@@ -183,6 +183,39 @@ def test_convnext_mlp_fused(C):
         o.convnext_mlp(dev(x, dt)[:100], dev(w1, dt), dev(b1), w2p, dev(b2), dev(gamma), out[:100], out[:100])
 
 
+def test_dwconv7_raw_stats_and_lnfold_gemm():
+    """LayerNorm deferred to the GEMM epilogue: dw7x7 raw output + slab moments, then fc1 with GP_EPI_LNFOLD_GELU must
+    reproduce gelu(fc1(LayerNorm(dwconv(x)))) (the ConvNeXt block front half)."""
+    o = ops()
+    dt = torch.float16
+    B, H, C, N = 4, 16, 512, 512
+    x = q(rnd(B, C, H, H, seed=91), dt)
+    wdw, bdw = q(rnd(C, 1, 7, 7, seed=92, scale=0.15), dt), rnd(C, seed=93, scale=0.5)
+    lw, lb = 1.0 + 0.3 * rnd(C, seed=94), 0.2 * rnd(C, seed=95)
+    w1, b1 = rnd(N, C, seed=96, scale=C ** -0.5), rnd(N, seed=97)
+    conv = F.conv2d(x, wdw, bdw, padding=3, groups=C).permute(0, 2, 3, 1)            # (B,H,W,C)
+    hid_ref = F.gelu(F.layer_norm(conv, (C,), lw, lb, 1e-6).reshape(-1, C) @ w1.t() + b1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    wt = wdw.reshape(C, 49).t().contiguous().to("cuda", dt)
+    y = torch.empty(B, H, H, C, dtype=dt, device="cuda")
+    stats = torch.zeros(B * H * H, 2, C // 128, device="cuda")
+    o.dwconv7_raw_stats(xd, wt, bdw.cuda(), y, stats)
+    assert rel_err(y, conv) < 2e-3
+    yr = y.float().cpu().reshape(-1, C // 128, 128)
+    assert torch.allclose(stats[:, 0].cpu(), yr.sum(-1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(stats[:, 1].cpu(), (yr * yr).sum(-1), rtol=1e-4, atol=1e-3)
+    wg = (w1 * lw[None, :]).to("cuda", dt)
+    cs = wg.float().sum(1).contiguous()
+    cb = (w1 @ lb + b1).cuda()
+    for variant in (0, 8, 10):
+        hid = torch.empty(B * H * H, N, dtype=dt, device="cuda")
+        o.gemm(y.view(-1, C), wg, hid, bias=cb, epilogue=o.EPI_LNFOLD_GELU, ln=(stats, cs, C // 128, 1e-6), variant=variant)
+        assert rel_err(hid, hid_ref) < 4e-3, variant
+    from givepose_amd._lib import GivePoseHipError
+    with pytest.raises(GivePoseHipError):     # M not a multiple of 256
+        o.gemm(y.view(-1, C)[:100], wg, hid[:100], bias=cb, epilogue=o.EPI_LNFOLD_GELU, ln=(stats, cs, C // 128, 1e-6))
+
+
 def test_gemm_rejects_bad_shapes():
     o = ops()
     from givepose_amd._lib import GivePoseHipError

@@ -80,6 +80,19 @@ def test_fp16_close_to_reference_golden(golden, net16, B):
     assert err["trans"] < 3e-2 * max(1.0, float(np.abs(z["out_trans"]).max()))
 
 
+@pytest.mark.parametrize("kw", [dict(defer_ln=True), dict(fuse_mlp=False)])
+def test_fp16_alternative_block_paths_close_to_reference_golden(golden, kw):
+    """The switchable ConvNeXt block paths (LayerNorm folded into fc1's epilogue at C = 512; unfused fc1 / fc2 at
+    C = 128 / 256) meet the same fp16 tolerances as the default wiring."""
+    z = golden("posenet_e2e_B4")
+    out = _model(torch.float16, **kw)(_batch(4, int(z["batch_seed"])), "cuda")
+    err = {k: float(np.abs(out[k].cpu().numpy() - z["out_" + k]).max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    print("fp16", kw, err)
+    assert err["nocs_coor"] < 2e-2 and err["ivfc_coor"] < 2e-2
+    assert err["rot"] < 3e-2 and err["size"] < 3e-2
+    assert err["trans"] < 3e-2 * max(1.0, float(np.abs(z["out_trans"]).max()))
+
+
 def test_graph_replay_equals_eager():
     from givepose_amd import PoseNet, PoseNetConfig
     net = PoseNet(PoseNetConfig(), dtype=torch.float16, seed=0, use_graph=True).cuda()
