@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--workload", default="full", choices=["full", "nodcn", "resnet34", "resnet34_nodcn", "att"],
                     help="full = reference wiring (ConvNeXt-B + DCNv3, BASELINE configs[2]); nodcn = use_dcn=''; "
                          "resnet34[_nodcn] = BASELINE configs[0-1] read literally (ResNet-34 trunk, not wired by the reference)")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent batches in flight per GPU (PoseNet slots: own buffers / hipGraph / stream, shared "
+                         "weights); 1 = strictly one step after the other")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -63,19 +66,29 @@ def main():
     cfg = PoseNetConfig(use_dcn="" if args.workload.endswith("nodcn") else "dcnv3",
                         main_backbone="resnet34" if args.workload.startswith("resnet34") else "convnext",
                         nocsmap_encoder="att" if args.workload == "att" else "conv")   # att = BASELINE configs[3] in-repo analogue
-    net = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph).to(dev)
-    static = net.static_inputs(B, dev)
+    NF = 1 if args.no_graph else max(1, args.inflight)      # slots need the graph path's per-slot streams
+    net = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph, inflight=NF).to(dev)
+    statics = [net.static_inputs(B, dev, slot=i) for i in range(NF)]
+    static = statics[0]
     host = synth.synth_batch(B, seed=1000 + rank)
-    for k, v in host.items():
-        static[k].copy_(torch.from_numpy(v).reshape(static[k].shape))
-    poses = torch.empty(B, gd.POSE_WIDTH, device=dev)
-    gathered = torch.empty(world * B, gd.POSE_WIDTH, device=dev) if world > 1 else None
+    for i, st in enumerate(statics):                        # every slot holds its own batch
+        hb = host if i == 0 else synth.synth_batch(B, seed=1000 + rank + 100 * i)
+        for k, v in hb.items():
+            st[k].copy_(torch.from_numpy(v).reshape(st[k].shape))
+    poses = [torch.empty(B, gd.POSE_WIDTH, device=dev) for _ in range(NF)]
+    gathered = [torch.empty(world * B, gd.POSE_WIDTH, device=dev) for _ in range(NF)] if world > 1 else None
+    counter = [0]
 
     def step():
-        out = net.forward_device(static, dev)
+        """One pass of the path over one batch; with NF > 1 consecutive steps use different slots and overlap on the
+        device (nothing is skipped: every step runs the whole launch sequence on its own buffers)."""
+        i = counter[0] % NF
+        counter[0] += 1
+        out = net.forward_device(statics[i], dev, slot=i, wait=NF == 1)
         if world > 1:
-            gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses)
-            gd.all_gather_poses(poses, world, out=gathered)
+            with torch.cuda.stream(net.stream(i) if NF > 1 else torch.cuda.current_stream(dev)):
+                gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses[i])
+                gd.all_gather_poses(poses[i], world, out=gathered[i])
         return out
 
     def fence():
@@ -84,7 +97,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 2)):      # first call eager (+ graph capture on the second)
+    for _ in range(max(args.warmup, 2 * NF)):  # per slot: first call eager, graph capture on the second
         step()
     fence()
     t0 = time.perf_counter()
@@ -112,9 +125,31 @@ def main():
                                   "ConvNeXt-B, not ResNet-34: SURVEY.md 0.2)"),
                    "batch_per_gpu": B, "global_batch": world * B, "img": "256x256", "parallelism": f"dp{world}",
                    "weights": "seeded random init (givepose_amd.synth, seed 0)", "hipgraph": not args.no_graph,
+                   "batches_in_flight": NF,
                    "collective": "all_gather (B,15) fp32 per rank" if world > 1 else "none"},
         "path_roofline_frac_mfma": round(value / world * GFLOP_PER_CROP[args.workload] * 1e9 / (PEAK_F16_TFLOPS * 1e12), 4),
     }
+
+    # the same K steps strictly one after the other (one batch in flight), for reference beside `value`
+    if NF > 1:
+        def step1():
+            out = net.forward_device(statics[0], dev, slot=0, wait=True)
+            if world > 1:
+                gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses[0])
+                gd.all_gather_poses(poses[0], world, out=gathered[0])
+        step1()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step1()
+        fence()
+        dt1 = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt1 = float(tt)
+        line["one_batch_in_flight"] = {"value": round(world * B * args.steps / dt1, 2), "unit": "images/s",
+                                       "ms_per_step": round(dt1 / args.steps * 1e3, 4)}
 
     # ---------------- roofline leg: per-launch hipEvents on the launch stream, eager pass
     if rank == 0 and not args.no_roofline:

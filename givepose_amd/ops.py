@@ -5,6 +5,7 @@ stream, writes into caller-provided (or freshly torch.empty'd) buffers and never
 PyTorch implementation: a missing library raises at import of the first op.
 """
 import ctypes
+import os
 
 import torch
 
@@ -56,13 +57,21 @@ _WS = {}
 
 
 def _workspace(device, nfloats):
-    ws = _WS.get(device)
+    """Split-K partial-sum workspace of the CURRENT stream: launches on different streams must not share one."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
         if ws is not None and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("split-K workspace too small during graph capture")
         ws = torch.empty(max(nfloats, 1 << 24), dtype=torch.float32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
+
+
+# Automatic split-K (skinny GEMMs: the PnP fc layers, feat_reducer) is switched off by PoseNet when several batches are
+# in flight: the two-kernel split-K path is then not needed for occupancy (another batch fills the chip) and, run
+# beside another batch's launches, it was the one ingredient of timing-dependent results on MI355X (DESIGN.md 6b).
+AUTO_SPLITK = True
 
 
 def auto_splitk(M, N, K, esz, n_cu=256):
@@ -102,7 +111,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz) if (variant in (0, 1) and gn is None and ln is None) else 1
+        splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 1) and gn is None and ln is None) else 1
     d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None

@@ -44,7 +44,7 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 
 class PoseNet(nn.Module):
-    def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None):
+    def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None, inflight=1):
         super().__init__()
         # the reference asserts backbone == 'convnext' (network/PoseNet.py:142); 'resnet34' (network/resnet.py:167-176,
         # defined but never wired there) is this build's throughput variant with feature_channel 512
@@ -70,8 +70,9 @@ class PoseNet(nn.Module):
                 aliases[key] = t
             _register(self, name, t, not is_buf)
         self._packed = None       # device-side packed weights
-        self._plans = {}          # B -> buffers / graph
-        self._stream = None       # dedicated stream of the hipGraph path
+        self.inflight = int(inflight)   # batches the caller keeps in flight (forward_device slots); > 1 turns split-K off
+        self._plans = {}          # (B, slot) -> buffers / graph
+        self._streams = {}        # slot -> dedicated stream of the hipGraph path
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -207,8 +208,8 @@ class PoseNet(nn.Module):
         return W
 
     # ------------------------------------------------------------------ buffers
-    def _plan(self, B, device):
-        plan = self._plans.get(B)
+    def _plan(self, B, device, slot=0):
+        plan = self._plans.get((B, slot))
         if plan is not None:
             return plan
         T, cfg = self.compute_dtype, self.cfg
@@ -262,7 +263,7 @@ class PoseNet(nn.Module):
         buf["hh"], buf["hz"] = f(B, 256), f(B, 256)
         buf["rot6d"], buf["pred_t"], buf["rot_allo"], buf["rot_ego"], buf["trans"] = f(B, 6), f(B, 3), f(B, 9), f(B, 9), f(B, 3)
         plan = {"buf": buf, "graph": None, "warm": False}
-        self._plans[B] = plan
+        self._plans[(B, slot)] = plan
         return plan
 
     # ------------------------------------------------------------------ launch sequence
@@ -317,6 +318,14 @@ class PoseNet(nn.Module):
         return x
 
     def _launch_all(self, B, plan):
+        prev_auto = ops.AUTO_SPLITK
+        ops.AUTO_SPLITK = self.inflight <= 1
+        try:
+            self._launch_seq(B, plan)
+        finally:
+            ops.AUTO_SPLITK = prev_auto
+
+    def _launch_seq(self, B, plan):
         W, buf, cfg = self._packed, plan["buf"], self.cfg
         dims, depths = cfg.convnext_dims, cfg.convnext_depths
         ops.mask_resize_nearest(buf["roi_mask"], buf["mask_out"])
@@ -427,25 +436,37 @@ class PoseNet(nn.Module):
     # ------------------------------------------------------------------ public API
     _INPUT_KEYS = ("roi_img", "roi_mask", "roi_coord_2d", "cam_K", "roi_wh", "bbox_center", "resize_ratio", "mean_size")
 
+    def stream(self, slot=0):
+        """The stream slot `slot`'s hipGraph is launched on (None before its first use / without use_graph)."""
+        return self._streams.get(slot)
+
     @torch.no_grad()
-    def forward_device(self, data, device="cuda"):
-        """Runs the path and returns views of the static output buffers, all on the device (no D->H sync)."""
+    def forward_device(self, data, device="cuda", slot=0, wait=True):
+        """Runs the path and returns views of the static output buffers, all on the device (no D->H sync).
+
+        slot / wait: independent batches in flight.  Every slot owns its buffers, hipGraph and stream (the packed
+        weights are shared); with ``wait=False`` the calling stream is not made to wait for the result, so forwards
+        of different slots overlap on the device -- the launches that cannot fill 256 CUs on their own (the 8x8 / 16x16
+        stages, the small heads, kernel tails) run beside another batch's.  The caller then orders its reads after
+        ``net.stream(slot)`` (or a device synchronise)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("givepose_amd.PoseNet runs on the HIP device only (no CPU path)")
+        if slot >= max(self.inflight, 1):
+            raise ValueError(f"slot {slot} needs PoseNet(..., inflight>={slot + 1})")
         _lib.load()
         if self._packed is None:
             self._pack(device)
         B = data["roi_img"].shape[0]
-        plan = self._plan(B, device)
+        plan = self._plan(B, device, slot)
         buf = plan["buf"]
         cur = torch.cuda.current_stream()
         if self.use_graph:
-            # hipGraph capture is not permitted on the legacy default stream: the graph path owns a stream
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=device)
-            self._stream.wait_stream(cur)
-            run_stream = self._stream
+            # hipGraph capture is not permitted on the legacy default stream: the graph path owns a stream (per slot)
+            if slot not in self._streams:
+                self._streams[slot] = torch.cuda.Stream(device=device)
+            run_stream = self._streams[slot]
+            run_stream.wait_stream(cur)
         else:
             run_stream = cur
         with torch.cuda.stream(run_stream):
@@ -469,18 +490,18 @@ class PoseNet(nn.Module):
             else:
                 self._launch_all(B, plan)
                 plan["warm"] = True
-        if run_stream is not cur:
+        if run_stream is not cur and wait:
             cur.wait_stream(run_stream)
         return {"rot": buf["rot_ego"].view(B, 3, 3), "trans": buf["trans"], "size": buf["size"], "mask": buf["mask_out"],
                 "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
                 "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf.get(f"x{len(self.cfg.convnext_dims) - 1}"),
                 "feat_cat": buf["feat_cat"]}
 
-    def static_inputs(self, B, device="cuda"):
+    def static_inputs(self, B, device="cuda", slot=0):
         """The plan's device-resident input buffers (fill these to skip the per-call H->D copies)."""
         if self._packed is None:
             self._pack(torch.device(device))
-        return {k: self._plan(B, torch.device(device))["buf"][k] for k in self._INPUT_KEYS}
+        return {k: self._plan(B, torch.device(device), slot)["buf"][k] for k in self._INPUT_KEYS}
 
     @torch.no_grad()
     def forward(self, data, device="cuda", do_loss=False, pred_scale=None):
