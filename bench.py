@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=["full", "nodcn", "resnet34", "resnet34_nodcn", "att"],
                     help="full = reference wiring (ConvNeXt-B + DCNv3, BASELINE configs[2]); nodcn = use_dcn=''; "
                          "resnet34[_nodcn] = BASELINE configs[0-1] read literally (ResNet-34 trunk, not wired by the reference)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches in flight per GPU (PoseNet slots: own buffers / hipGraph / stream, shared "
                          "weights); 1 = strictly one step after the other")
     ap.add_argument("--no-graph", action="store_true")

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-kernel-class HBM traffic.
 
-  python scripts/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out.json>
+  python scripts/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out.json> [steps profiled]
+
+(steps profiled = forward passes each rocprofv3 run executed, e.g. 4 for bench.py --steps 2 --warmup 1 --no-graph
+--no-roofline --no-cpu-baseline --inflight 1: max(warmup, 2) + steps; gives hbm_bytes_per_step)
 
 Correction (guides/MI355X_MICROARCH.md, HBM section): both counters are in KB; on gfx950 FETCH_SIZE tallies 128-B
 requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled here; WRITE_SIZE is exact.
 """
 import collections, csv, glob, json, sys
 
-CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce")), ("dcnv3", ("dcnv3_",)),
+CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce", "convnext_mlp_kernel")), ("dcnv3", ("dcnv3_",)),
          ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
          ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
          ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
@@ -30,6 +33,7 @@ def load(d, counter):
 
 
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 res = {}
 for cls, _ in CLASS:
     if cls in fe and cls in wr and fe[cls][0]:
@@ -37,8 +41,8 @@ for cls, _ in CLASS:
         rd = 2.0 * fe[cls][1] * 1024 / n          # gfx950 correction: x2
         wb = wr[cls][1] * 1024 / wr[cls][0]
         res[cls] = {"launches_profiled": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb,
-                    "hbm_bytes_per_launch": rd + wb}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph, bs=64 fp16",
+                    "hbm_bytes_per_launch": rd + wb, "hbm_bytes_per_step": (rd + wb) * n / steps}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline --inflight 1, bs=64 fp16",
            "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "classes": res},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))
