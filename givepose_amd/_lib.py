@@ -25,7 +25,8 @@ class GemmDesc(Structure):
                 ("B", c_int), ("H", c_int), ("Win", c_int), ("Cin", c_int), ("KH", c_int), ("KW", c_int),
                 ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
                 ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int),
-                ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float)]
+                ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
+                ("co_scheduled", c_int)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)

@@ -886,6 +886,11 @@ static bool pp_enabled() {
     return on;
 }
 
+static long pp_min_tiles() {
+    const char* e = getenv("GP_GEMM_PP_MIN_TILES");
+    return e ? atol(e) : 192;
+}
+
 extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(d != nullptr, "gp_gemm: null descriptor");
     GP_REQUIRE(d->dtype == GP_F32 || d->dtype == GP_F16, "gp_gemm: bad dtype %d", d->dtype);
@@ -960,7 +965,13 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K stays on the register-staged kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
         if (p.splitk > 1) variant = 1;
-        else if (d->dtype == GP_F16) variant = (d->N % 256 == 0 && (tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU)) ? ((d->K >= 512 && pp_enabled()) ? 10 : 8) : 7;
+        else if (d->dtype == GP_F16) {
+            // co_scheduled (several batches in flight: PoseNet(inflight > 1)): a launch need not fill the chip by itself,
+            // the 256x256 ping-pong tile is then the cheapest per FLOP even for 32-128 tiles (GP_GEMM_PP_MIN_TILES: A/B)
+            const bool fills = tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU;
+            if (d->N % 256 == 0 && d->K >= 512 && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
+        }
         else variant = 4;
     }
     GP_REQUIRE(variant >= 1 && variant <= 12 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);

@@ -888,6 +888,11 @@ bool ct_ok(int C, int esz) {
 
 }  // namespace
 
+static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
+    static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
+    return on;
+}
+
 extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w,
                             const float* ln_b, void* y, int B, int H, int W, int C, int KS, float eps, int act,
                             long n_pixels, int dtype, void* stream) {
@@ -909,7 +914,7 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
         (C == 128 || C == 256 || C == 512)) {
         if (C == 128) launch_dw7_mfma<1, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if (C == 256) launch_dw7_mfma<2, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-        else if ((long)B * (H / 4) * (W / 16) >= 512) launch_dw7_mfma<4, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+        else if ((long)B * (H / 4) * (W / 16) >= 512 || dw_single_buffer()) launch_dw7_mfma<4, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else launch_dw7_mfma<4, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }

@@ -72,6 +72,8 @@ def _workspace(device, nfloats):
 # in flight: the two-kernel split-K path is then not needed for occupancy (another batch fills the chip) and, run
 # beside another batch's launches, it was the one ingredient of timing-dependent results on MI355X.
 AUTO_SPLITK = True
+# set beside it: tells gp_gemm that other launches run next to this one (tile chosen per FLOP, not to fill the chip)
+CO_SCHEDULED = False
 
 
 def auto_splitk(M, N, K, esz, n_cu=256):
@@ -121,6 +123,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
+    d.co_scheduled = 1 if CO_SCHEDULED else 0
     if ln is not None:       # (row moments (M,2,nslab), column sums of w, nslab, eps): EPI_LNFOLD_GELU
         d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2], ln[3]
     if gn is not None:       # (partial buffer, groups, pixels per image): fused GroupNorm statistics of the output

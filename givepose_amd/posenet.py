@@ -318,12 +318,12 @@ class PoseNet(nn.Module):
         return x
 
     def _launch_all(self, B, plan):
-        prev_auto = ops.AUTO_SPLITK
-        ops.AUTO_SPLITK = self.inflight <= 1
+        prev = ops.AUTO_SPLITK, ops.CO_SCHEDULED
+        ops.AUTO_SPLITK, ops.CO_SCHEDULED = self.inflight <= 1, self.inflight > 1
         try:
             self._launch_seq(B, plan)
         finally:
-            ops.AUTO_SPLITK = prev_auto
+            ops.AUTO_SPLITK, ops.CO_SCHEDULED = prev
 
     def _launch_seq(self, B, plan):
         W, buf, cfg = self._packed, plan["buf"], self.cfg

@@ -108,6 +108,9 @@ typedef struct gp_gemm_desc {
     const float* ln_colsum;
     int ln_nslab;
     float ln_eps;
+    /* != 0: the caller keeps other launches running beside this one (independent batches in flight), so the tile is
+     * chosen for cost per FLOP rather than for filling 256 CUs alone (variant == 0 only) */
+    int co_scheduled;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 
