@@ -57,7 +57,12 @@ def main():
     from givepose_amd import dist as gd
     import torch.distributed as dist
 
-    rank, local, world = gd.init_from_env()
+    # GP_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (gloo backend, every rank on cuda:0);
+    # the numbers mean nothing, the driver's real runs use RCCL with one rank per GPU
+    rehearse = os.environ.get("GP_BENCH_REHEARSE") == "1"
+    rank, local, world = gd.init_from_env(backend="gloo" if rehearse else None)
+    if rehearse:
+        local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
