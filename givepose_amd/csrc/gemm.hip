@@ -870,6 +870,186 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     }
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolution with Cout = 256 on the ping-pong schedule, X staged as an LDS WINDOW.
+// The implicit-GEMM kernels above fetch the X rows of every filter tap separately: 9 x 16 KB of LDS-DMA per 32-channel
+// chunk and tile, although the nine taps read the same (TR + 2) x (W + 2) pixel window shifted by (kh, kw).  The
+// per-CU LDS-DMA rate (~53 GB/s) is what bounds the 256 x 256 tile, so here the K loop runs channel chunk OUTER /
+// tap INNER: the window of a chunk (<= 25 KB, halo and image border from the zero page) is fetched ONCE, double
+// buffered against the previous chunk, and the nine taps read their B fragments from it at shifted pixel positions
+// (16 consecutive window pixels per fragment; bit 1 of the 16-byte channel slot is XOR-ed with bit 2 of the window pixel
+// index: the one swizzle family -- found by enumeration over the ds_read_b128 lane groups {0-3,12-15,20-27}, ... --
+// that keeps every lane group on 16 different slots for EVERY pixel alignment, i.e. for all nine tap shifts).  W still streams tap by tap through
+// the 4-stage ring.  DMA bytes per tile: 8 x (25 + 144) KB instead of 8 x 288 KB.
+// Tile = 256 output pixels = TR whole image rows (W in {64, 32, 16}); 8 waves, two ping-pong groups as above.
+__device__ __forceinline__ void wait_vmcnt(int n) {   // s_waitcnt takes an immediate: wave-uniform dispatch on n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    }
+}
+
+template <int WIMG, int NS>
+__global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
+    constexpr int MT = 8, NT = 4, BM = 256, BN = 256, LEAD = NS - 2;
+    // window row pitch WW: a multiple of 8 pixels, so that a kh shift never changes bit 2 of the window pixel index
+    // (the swizzle bit) and the nine tap addresses of an m-tile are 3 registers (one per kw) + an immediate offset
+    constexpr int TR = BM / WIMG, WW = (WIMG + 2 + 7) / 8 * 8, NP = (TR + 2) * WW, NI = (NP + 15) / 16;
+    constexpr int WINB = 32768, WST = BN * 64;     // two window buffers, 32 KB apart
+    static_assert(NI * 1024 <= WINB, "window");
+    constexpr int WIN0 = NS * WST;
+    constexpr int SMEM = WIN0 + 2 * WINB;
+    static_assert(SMEM >= 8 * 9216 && SMEM <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1, grp = wave >> 2;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int nblk = p.tiles_m;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int m0 = tile * BM;
+    const int img = m0 / (p.H * WIMG), h0 = (m0 - img * p.H * WIMG) / WIMG;
+    const int Cin = p.Cin, NCC = Cin >> 5, NSTG = 9 * NCC;
+
+    const half_t* __restrict__ X = reinterpret_cast<const half_t*>(p.X);
+    const half_t* __restrict__ W = reinterpret_cast<const half_t*>(p.W);
+    const char* zp = reinterpret_cast<const char*>(gp_zero_page_tu);
+
+    // ---- DMA sources
+    const int lrow = lane >> 2;
+    const int wchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
+    const char* wptr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        wptr[i] = reinterpret_cast<const char*>(W + (long)((i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8);
+    const char* xsrc[4];     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3
+    unsigned xvalid = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = wave + 8 * j, px = i * 16 + lrow;
+        const int wy = px / WW, wx = px - wy * WW;
+        const int gy = h0 - 1 + wy, gx = wx - 1;
+        const int lc = (lane & 3) ^ (((px >> 2) & 1) << 1);
+        const bool ok = i < NI && px < NP && wx < WIMG + 2 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)WIMG;
+        xsrc[j] = ok ? reinterpret_cast<const char*>(X + (((long)img * p.H + gy) * WIMG + gx) * Cin + lc * 8) : zp;
+        if (ok) xvalid |= 1u << j;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    auto stage_w = [&](int buf, int cc, int tap) {      // W rows of K step (cc, tap): k offset tap * Cin + cc * 32
+        const int off = (tap * Cin + cc * 32) * 2;
+        const unsigned d = lds0 + buf * WST + wave * 1024;
+        glds16(wptr[0] + off, d);
+        glds16(wptr[1] + off, d + 8192);
+    };
+    auto stage_x = [&](int j, int cc) {        // one 16-pixel piece of the window of chunk cc
+        const unsigned d = lds0 + WIN0 + (cc & 1) * WINB + (wave + 8 * j) * 1024;
+        glds16((xvalid >> j) & 1 ? xsrc[j] + cc * 64 : zp, d);
+    };
+
+    // ---- accumulators (bias as the initial value: the lean epilogue is the only one here)
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + a * 16 + fq * 4);
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = init;
+    }
+    // LDS byte address of this lane's B fragment per m-tile and kw (tap row kh adds kh * WW * 64 as an immediate)
+    unsigned xa[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int ml = wm * 128 + mt * 16 + fr;
+        const int pb = (ml / WIMG) * WW + (ml % WIMG);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int px = pb + kw;
+            xa[mt][kw] = WIN0 + px * 64 + ((fq ^ (((px >> 2) & 1) << 1)) << 4);   // offset into smem
+        }
+    }
+    const int wfo = (wn * 64 + fr) * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+
+    // ---- prologue: window of chunk 0, W of steps 0 and 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (wave + 8 * j < NI) stage_x(j, 0);
+#pragma unroll
+    for (int i = 0; i < LEAD; ++i) stage_w(i, 0, i);
+    wait_vmcnt(2 * (LEAD - 1));
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+
+    uint4 xf[MT], wf[NT];
+    int st = 0, rbuf = 0, wbuf = LEAD, ops1 = 2, ops2 = 2;   // DMA ops issued one / two phases ago (W of steps 1..LEAD-1 at first)
+    for (int cc = 0; cc < NCC; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++st) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const char* ws = smem + rbuf * WST + wfo;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 1024);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xf[mt] = *reinterpret_cast<const uint4*>(smem + xa[mt][kw] + kh * WW * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA: one window piece of the NEXT chunk during taps 1..4 (its buffer was last read in chunk cc - 1, whose
+            // reads are two barriers back by tap 1), then the W rows of step st + 2; then wait for the own W of st + 1
+            bool xi = false;
+            if (tap >= 1 && tap <= 4) {
+                xi = cc + 1 < NCC && wave + 8 * (tap - 1) < NI && p.dbg != 1;
+                if (xi) stage_x(tap - 1, cc + 1);
+            }
+            const bool wi = st + LEAD < NSTG && p.dbg != 1;
+            if (wi) stage_w(wbuf, cc + (tap + LEAD) / 9, (tap + LEAD) % 9);
+            // the own W rows of step st + 1 have landed once at most the ops issued after them are outstanding: those of
+            // this phase and (LEAD = 3) of the previous one (vmcnt retires in issue order, the window pieces included)
+            const int ops0 = (wi ? 2 : 0) + (xi ? 1 : 0);
+            wait_vmcnt(LEAD == 3 ? ops0 + ops1 : ops0);
+            ops2 = ops1; ops1 = ops0;
+            rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
+            wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mma<half_t>(acc[nt][mt], wf[nt], xf[mt]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xa[mt][kw] += (cc & 1) ? -WINB : WINB;     // the other window buffer
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+
+    char* slab = smem + wave * 9216;
+    const int mb = m0 + wm * 128, nb = wn * 64;
+    switch (p.epi) {
+        case GP_EPI_GELU: epilogue_lean<MT, NT, GP_EPI_GELU>(p, acc, slab, mb, nb, lane); break;
+        case GP_EPI_RELU: epilogue_lean<MT, NT, GP_EPI_RELU>(p, acc, slab, mb, nb, lane); break;
+        default: epilogue_lean<MT, NT, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
+    }
+}
+
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
@@ -883,6 +1063,11 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
 // A/B switch for bench runs on one device: GP_GEMM_PP=0 keeps the ping-pong kernel out of the automatic choice
 static bool pp_enabled() {
     static const bool on = [] { const char* e = getenv("GP_GEMM_PP"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+static bool conv_window_enabled() {   // A/B switch: GP_CONV_WINDOW=0 keeps 3x3 convs on the tap-by-tap ping-pong kernel
+    static const bool on = [] { const char* e = getenv("GP_CONV_WINDOW"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -974,7 +1159,28 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         }
         else variant = 4;
     }
-    GP_REQUIRE(variant >= 1 && variant <= 12 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    // 3x3 s1 p1, Cout 256, whole image rows per 256-pixel tile: the LDS-window kernel (variant 13; automatic when the
+    // ping-pong kernel would have been chosen)
+    const bool win_ok = d->dtype == GP_F16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->N == 256 &&
+                        d->Cin % 32 == 0 && (d->Win == 64 || d->Win == 32 || d->Win == 16) && d->H % (256 / d->Win) == 0 &&
+                        !d->out_f32 && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 &&
+                        (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
+    if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
+    GP_REQUIRE(variant >= 1 && variant <= 13 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    if (variant == 13) {
+        GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
+        p.tiles_m = d->M / 256;
+        p.tiles_n = 1;
+        // 4-stage W ring, DMA lead 2 (the 5-stage / lead-3 instantiation measured 1.6x slower: dbg 7 keeps it for A/B)
+        if (p.dbg == 7) {
+            if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
+            else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv3_pp_kernel<16, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        } else if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3_pp_kernel<16, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     if (variant == 12) {   // as 10 with a 5-stage ring (all 160 KB of LDS), DMA lead 3
         if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 5, false, 64, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");

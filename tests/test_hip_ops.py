@@ -216,6 +216,39 @@ def test_dwconv7_raw_stats_and_lnfold_gemm():
         o.gemm(y.view(-1, C)[:100], wg, hid[:100], bias=cb, epilogue=o.EPI_LNFOLD_GELU, ln=(stats, cs, C // 128, 1e-6))
 
 
+@pytest.mark.parametrize("cfg", [dict(B=3, H=64, Cin=256), dict(B=5, H=32, Cin=256), dict(B=6, H=16, Cin=64), dict(B=2, H=32, Cin=128)])
+def test_conv3x3_lds_window_kernel(cfg):
+    """3x3 s1 p1 conv, Cout 256, X staged as an LDS window (variant 13; chunk-outer / tap-inner K order): against
+    F.conv2d and against the tap-by-tap ping-pong kernel; image borders, several images per launch, fused GroupNorm
+    statistics, every epilogue it supports; repeated launches are bit-identical (race screen)."""
+    o = ops()
+    dt = torch.float16
+    B, H, Cin = cfg["B"], cfg["H"], cfg["Cin"]
+    x = q(rnd(B, Cin, H, H, seed=101), dt)
+    w = q(rnd(256, Cin, 3, 3, seed=102, scale=(Cin * 9) ** -0.5), dt)
+    b = rnd(256, seed=103)
+    lin = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1)
+    xp = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    wp = w.permute(0, 2, 3, 1).reshape(256, -1).contiguous().to("cuda", dt)
+    for epi, ref in ((o.EPI_NONE, lin), (o.EPI_GELU, F.gelu(lin)), (o.EPI_RELU, F.relu(lin))):
+        out = o.conv2d_nhwc(xp, wp, 3, 3, 1, 1, bias=b.cuda(), epilogue=epi, variant=13)
+        assert rel_err(out, ref) < TOL[dt], (cfg, epi)
+        for _ in range(3):
+            assert torch.equal(o.conv2d_nhwc(xp, wp, 3, 3, 1, 1, bias=b.cuda(), epilogue=epi, variant=13), out)
+    # fused GroupNorm statistics: same numbers as the ping-pong kernel's epilogue (the statistics are those of the
+    # rounded outputs, which may differ in the last fp16 bit between the two K orders)
+    G, hw = 32, H * H
+    pa = torch.zeros(B * (hw // 64) * G * 2, device="cuda")
+    pb = torch.zeros_like(pa)
+    ya = o.conv2d_nhwc(xp, wp, 3, 3, 1, 1, variant=13, gn=(pa, G, hw))
+    yb = o.conv2d_nhwc(xp, wp, 3, 3, 1, 1, variant=10, gn=(pb, G, hw))
+    assert rel_err(ya, yb.float().cpu()) < 2e-3
+    assert torch.allclose(pa, pb, rtol=2e-3, atol=5e-2)
+    from givepose_amd._lib import GivePoseHipError
+    with pytest.raises(GivePoseHipError):     # Cout != 256
+        o.conv2d_nhwc(xp, wp[:128].contiguous(), 3, 3, 1, 1, variant=13)
+
+
 def test_gemm_rejects_bad_shapes():
     o = ops()
     from givepose_amd._lib import GivePoseHipError
