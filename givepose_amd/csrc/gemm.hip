@@ -475,6 +475,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: a K step then costs one
+// scalar add per operand instead of a 64-bit vector add + select per instruction (the load phase of the ping-pong
+// schedule issues its VALU work beside the partner wave's MFMAs, at half rate)
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP p) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
@@ -654,9 +665,35 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         const int grp = wave >> 2;
         const int co = (fq ^ ((-(fr >> 2)) & 3)) << 4;
         uint4 xf[MT], wf[NT];
+        // plain GEMM: scalar-base DMA.  Rows past the M / N edge are clamped to the last valid row (their products are
+        // never stored), so no zero page and no per-lane select is needed.
+        const bool sdma = !p.conv && (long)BM * p.ldx * sizeof(T) < (1l << 31) && (long)BN * p.K * sizeof(T) < (1l << 31);
+        unsigned xo[XI], wo[WI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int r = min((i * NW + wave) * RPI + lrow, p.M - 1 - m0);
+            xo[i] = (unsigned)(((long)r * p.ldx + lchunk * EPT) * sizeof(T));
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int r = min((i * NW + wave) * RPI + lrow, p.N - 1 - n0);
+            wo[i] = (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
+        }
+        const char* xtile = reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
+        const char* wtile = reinterpret_cast<const char*>(W + (long)n0 * p.K);
+        auto stage_s = [&](int buf, int kt) {
+            const unsigned xs = lds0 + buf * STAGE + wave * 1024;
+            const unsigned ws = xs + BM * RB;
+            const char* bx = xtile + (long)kt * RB;
+            const char* bw = wtile + (long)kt * RB;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) glds16_s(bx, xo[i], xs + i * NW * 1024);
+#pragma unroll
+            for (int i = 0; i < WI; ++i) glds16_s(bw, wo[i], ws + i * NW * 1024);
+        };
 #pragma unroll
         for (int i = 0; i < LEAD; ++i)
-            if (i < p.nkt) stage(i, i);
+            if (i < p.nkt) { if (sdma) stage_s(i, i); else stage(i, i); }
         // wait for step 0 (the load phase of step t waits for step t+1)
         if constexpr (LEAD == 3) {
             if (p.nkt >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
@@ -679,7 +716,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 1024 + co);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + LEAD < p.nkt && (p.dbg != 1 || kt + LEAD < NS)) stage(nbuf, kt + LEAD);
+            if (kt + LEAD < p.nkt && (p.dbg != 1 || kt + LEAD < NS)) { if (sdma) stage_s(nbuf, kt + LEAD); else stage(nbuf, kt + LEAD); }
             // own DMA of step t+1 landed; steps t+2 .. t+LEAD stay in flight
             if (LEAD == 3 && kt + 3 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
             else if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
@@ -930,10 +967,9 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     // ---- DMA sources
     const int lrow = lane >> 2;
     const int wchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
-    const char* wptr[2];
+    unsigned woff[2];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        wptr[i] = reinterpret_cast<const char*>(W + (long)((i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8);
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)((((i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
     const char* xsrc[4];     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3
     unsigned xvalid = 0;
 #pragma unroll
@@ -948,10 +984,10 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
     auto stage_w = [&](int buf, int cc, int tap) {      // W rows of K step (cc, tap): k offset tap * Cin + cc * 32
-        const int off = (tap * Cin + cc * 32) * 2;
+        const char* base = reinterpret_cast<const char*>(W) + (tap * Cin + cc * 32) * 2;
         const unsigned d = lds0 + buf * WST + wave * 1024;
-        glds16(wptr[0] + off, d);
-        glds16(wptr[1] + off, d + 8192);
+        glds16_s(base, woff[0], d);
+        glds16_s(base, woff[1], d + 8192);
     };
     auto stage_x = [&](int j, int cc) {        // one 16-pixel piece of the window of chunk cc
         const unsigned d = lds0 + WIN0 + (cc & 1) * WINB + (wave + 8 * j) * 1024;
