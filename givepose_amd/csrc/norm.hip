@@ -350,23 +350,38 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     const half_t* xb = x + (long)b * H * W * C;
     const half_t* zero = reinterpret_cast<const half_t*>(gp_zero_page_tu);
 
+    // DMA sources of slab 0, computed once: the halo pixel of a lane does not depend on the slab (only + 256 B per slab)
+    constexpr int XPW = (IN_INSTR + 7) / 8, WPW = (W_INSTR + 7) / 8;
+    const half_t* xsrc0[XPW];
+    const half_t* wsrc0[WPW];
+    unsigned xok = 0, wok = 0;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        const int ins = wave + 8 * j;
+        const int i = ins * 64 + lane, px = i >> 4, ps = i & 15;
+        const int iy = px / IW, ix = px - iy * IW;
+        const int gy = h0 - R + iy, gx = w0 - R + ix;
+        const int ls = ps ^ ((ix & 7) << 1);
+        const bool ok = ins < IN_INSTR && px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        xsrc0[j] = ok ? xb + ((long)gy * W + gx) * C + slab0 * 128 + ls * 8 : zero;
+        if (ok) xok |= 1u << j;
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int ins = wave + 8 * j;
+        const int i = ins * 64 + lane, tap = i >> 4, sl = i & 15;
+        const bool ok = ins < W_INSTR && tap < 49;
+        wsrc0[j] = ok ? wt + (long)tap * C + slab0 * 128 + sl * 8 : zero;
+        if (ok) wok |= 1u << j;
+    }
     auto issue = [&](int s, int buf) {
         const unsigned base = lds0 + buf * BUF;
-        for (int ins = wave; ins < IN_INSTR; ins += 8) {
-            const int i = ins * 64 + lane, px = i >> 4, ps = i & 15;
-            const int iy = px / IW, ix = px - iy * IW;
-            const int gy = h0 - R + iy, gx = w0 - R + ix;
-            const int ls = ps ^ ((ix & 7) << 1);
-            const half_t* src = zero;
-            if (px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-                src = xb + ((long)gy * W + gx) * C + (slab0 + s) * 128 + ls * 8;
-            glds16_n(src, base + ins * 1024);
-        }
-        for (int ins = wave; ins < W_INSTR; ins += 8) {
-            const int i = ins * 64 + lane, tap = i >> 4, sl = i & 15;
-            const half_t* src = tap < 49 ? wt + (long)tap * C + (slab0 + s) * 128 + sl * 8 : zero;
-            glds16_n(src, base + (IN_INSTR + ins) * 1024);
-        }
+#pragma unroll
+        for (int j = 0; j < XPW; ++j)
+            if (wave + 8 * j < IN_INSTR) glds16_n((xok >> j) & 1 ? xsrc0[j] + s * 128 : zero, base + (wave + 8 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            if (wave + 8 * j < W_INSTR) glds16_n((wok >> j) & 1 ? wsrc0[j] + s * 128 : zero, base + (IN_INSTR + wave + 8 * j) * 1024);
     };
     {
         const int pin = par_bytes / 1024;
