@@ -11,7 +11,7 @@ requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled 
 """
 import collections, csv, glob, json, sys
 
-CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce", "convnext_mlp_kernel")), ("dcnv3", ("dcnv3_",)),
+CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
          ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
          ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
          ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
