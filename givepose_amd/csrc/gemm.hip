@@ -970,8 +970,11 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     unsigned woff[2];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
 #pragma unroll
     for (int i = 0; i < 2; ++i) woff[i] = (unsigned)((((i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
-    const char* xsrc[4];     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3
+    // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3.  32-bit byte offsets from the
+    // image base (scalar); halo / border lanes point at the zero page instead (xvalid)
+    unsigned xoff[4];
     unsigned xvalid = 0;
+    const char* ximg = reinterpret_cast<const char*>(X + (long)img * p.H * WIMG * Cin);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = wave + 8 * j, px = i * 16 + lrow;
@@ -979,7 +982,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         const int gy = h0 - 1 + wy, gx = wx - 1;
         const int lc = (lane & 3) ^ (((px >> 2) & 1) << 1);
         const bool ok = i < NI && px < NP && wx < WIMG + 2 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)WIMG;
-        xsrc[j] = ok ? reinterpret_cast<const char*>(X + (((long)img * p.H + gy) * WIMG + gx) * Cin + lc * 8) : zp;
+        xoff[j] = ok ? (unsigned)(((gy * WIMG + gx) * Cin + lc * 8) * 2) : 0u;
         if (ok) xvalid |= 1u << j;
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
@@ -991,7 +994,8 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     };
     auto stage_x = [&](int j, int cc) {        // one 16-pixel piece of the window of chunk cc
         const unsigned d = lds0 + WIN0 + (cc & 1) * WINB + (wave + 8 * j) * 1024;
-        glds16((xvalid >> j) & 1 ? xsrc[j] + cc * 64 : zp, d);
+        const char* src = ximg + xoff[j] + cc * 64;
+        glds16((xvalid >> j) & 1 ? src : zp, d);
     };
 
     // ---- accumulators (bias as the initial value: the lean epilogue is the only one here)
