@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
 }
 
 // One wavefront per output pixel; G == 4, D == 64 (lane = g*16 + cv), P <= 16.
-template <typename T, typename OT>
+// KS > 0: kernel size known at compile time and remove_center == 0 (the PoseNet geometry is KS = 3): the tap loops
+// unroll and the (tap index -> i, j) bookkeeping disappears; the arithmetic per tap is the same expression.
+template <typename T, typename OT, int KS = 0>
 __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -134,7 +136,8 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     const long t2 = r / p.Wo;
     const int ho = (int)(t2 % p.Ho);
     const int b = (int)(t2 / p.Ho);
-    const int P = p.K * p.K - p.rc;
+    const int K = KS > 0 ? KS : p.K, rc = KS > 0 ? 0 : p.rc;
+    const int P = K * K - rc;
     // lane t < P of row g owns tap t
     float ow = 0.f, oh = 0.f, mk = p.logits ? -INFINITY : 0.f;
     if (t < P) {
@@ -149,28 +152,52 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
         const float s = group_sum(e, 16);
         mk = e / s;
     }
-    const int halfk = (p.dil * (p.K - 1)) >> 1;
+    const int halfk = (p.dil * (K - 1)) >> 1;
     const float p0_w_ = (float)(halfk - p.pad + wo * p.stride) - halfk * p.os;
     const float p0_h_ = (float)(halfk - p.pad + ho * p.stride) - halfk * p.os;
     const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * 256 + lane * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int q = 0;
-    for (int i = 0; i < p.K; ++i)
-        for (int j = 0; j < p.K; ++j) {
-            if (p.rc && i == p.K / 2 && j == p.K / 2) continue;
-            const int src = (lane & 48) | q;  // tap q's owner inside this 16-lane row
-            const float tw = __shfl(ow, src, 64), th = __shfl(oh, src, 64), wgt = __shfl(mk, src, 64);
+    if constexpr (KS > 0) {
+        // tap q's (offset_w, offset_h, weight) from its owner lane q of this 16-lane row: DPP row_share, no LDS crossbar
+#define GP_ROWSHARE(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
+        auto tap = [&](float tw, float th, float wgt, int i, int j) {
             const float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
             const float loc_h = p0_h_ + (j * p.dil + th) * p.os;
             if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)p.H && loc_w < (float)p.W)
                 bilinear4<T>(im, p.H, p.W, 256, loc_h, loc_w, wgt, acc);
-            ++q;
-        }
+        };
+        static_assert(KS == 3, "row_share immediates are spelled out for 3x3");
+        tap(GP_ROWSHARE(ow, 0), GP_ROWSHARE(oh, 0), GP_ROWSHARE(mk, 0), 0, 0);
+        tap(GP_ROWSHARE(ow, 1), GP_ROWSHARE(oh, 1), GP_ROWSHARE(mk, 1), 0, 1);
+        tap(GP_ROWSHARE(ow, 2), GP_ROWSHARE(oh, 2), GP_ROWSHARE(mk, 2), 0, 2);
+        tap(GP_ROWSHARE(ow, 3), GP_ROWSHARE(oh, 3), GP_ROWSHARE(mk, 3), 1, 0);
+        tap(GP_ROWSHARE(ow, 4), GP_ROWSHARE(oh, 4), GP_ROWSHARE(mk, 4), 1, 1);
+        tap(GP_ROWSHARE(ow, 5), GP_ROWSHARE(oh, 5), GP_ROWSHARE(mk, 5), 1, 2);
+        tap(GP_ROWSHARE(ow, 6), GP_ROWSHARE(oh, 6), GP_ROWSHARE(mk, 6), 2, 0);
+        tap(GP_ROWSHARE(ow, 7), GP_ROWSHARE(oh, 7), GP_ROWSHARE(mk, 7), 2, 1);
+        tap(GP_ROWSHARE(ow, 8), GP_ROWSHARE(oh, 8), GP_ROWSHARE(mk, 8), 2, 2);
+#undef GP_ROWSHARE
+    } else {
+        int q = 0;
+        for (int i = 0; i < p.K; ++i)
+            for (int j = 0; j < p.K; ++j) {
+                if (p.rc && i == p.K / 2 && j == p.K / 2) continue;
+                const int src = (lane & 48) | q;  // tap q's owner inside this 16-lane row
+                const float tw = __shfl(ow, src, 64), th = __shfl(oh, src, 64), wgt = __shfl(mk, src, 64);
+                const float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
+                const float loc_h = p0_h_ + (j * p.dil + th) * p.os;
+                if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)p.H && loc_w < (float)p.W)
+                    bilinear4<T>(im, p.H, p.W, 256, loc_h, loc_w, wgt, acc);
+                ++q;
+            }
+    }
     st4(reinterpret_cast<T*>(p.out) + r * 256 + lane * 4, acc);
 }
 
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
-    if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {
+    if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
+        hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
+    } else if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
     } else {
         const long total = p.rows * p.G * (p.D / 4);
