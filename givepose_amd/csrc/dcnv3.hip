@@ -77,6 +77,37 @@ __device__ __forceinline__ void bilinear4(const T* im, int H, int W, int cstride
     }
 }
 
+// Branch-free form for the wave kernel: the four corner fetches are issued unconditionally from CLAMPED coordinates and
+// an out-of-range corner gets weight zero (same sum as the reference, which skips it: dcnv3_im2col_cuda.cuh:57-78);
+// the products are written as fma(w, (float)half, acc) so that hipcc emits v_fma_mix_f32 (fp16 operand converted inside
+// the FMA) instead of a v_cvt_f32_f16 per corner value, and there is no branch between the loads of consecutive taps.
+template <typename T>
+__device__ __forceinline__ void bilinear4_nb(const T* im, unsigned lane4, int H, int W, float Hf, float Wf, float h, float w, float wgt, float* acc) {
+    const float fh = floorf(h), fw = floorf(w);
+    const float lh = h - fh, lw = w - fw, hh = 1.f - lh, hw = 1.f - lw;
+    const int h_low = (int)fh, w_low = (int)fw;          // in (-2, H) x (-2, W): the caller's range test guarantees it
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const bool hl = h_low >= 0, hhi = h_high <= H - 1, wl = w_low >= 0, whi = w_high <= W - 1;
+    const float w1 = (hl && wl) ? hh * hw : 0.f, w2 = (hl && whi) ? hh * lw : 0.f;
+    const float w3 = (hhi && wl) ? lh * hw : 0.f, w4 = (hhi && whi) ? lh * lw : 0.f;
+    const int y0 = max(h_low, 0), y1 = min(h_high, H - 1), x0 = max(w_low, 0), x1 = min(w_high, W - 1);
+    // 32-bit byte offsets from the (wave-uniform) image base: scalar-base loads, no 64-bit vector address arithmetic
+    const unsigned r0 = (unsigned)(y0 * W) * 256u + lane4, r1 = (unsigned)(y1 * W) * 256u + lane4;
+    const char* base = reinterpret_cast<const char*>(im);
+    const Ch4<T> v1 = ld4(reinterpret_cast<const T*>(base + (size_t)((r0 + x0 * 256u) * (unsigned)sizeof(T)))),
+                 v2 = ld4(reinterpret_cast<const T*>(base + (size_t)((r0 + x1 * 256u) * (unsigned)sizeof(T)))),
+                 v3 = ld4(reinterpret_cast<const T*>(base + (size_t)((r1 + x0 * 256u) * (unsigned)sizeof(T)))),
+                 v4 = ld4(reinterpret_cast<const T*>(base + (size_t)((r1 + x1 * 256u) * (unsigned)sizeof(T))));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float t = w1 * v1.get(c);
+        t = fmaf(w2, v2.get(c), t);
+        t = fmaf(w3, v3.get(c), t);
+        t = fmaf(w4, v4.get(c), t);
+        acc[c] = fmaf(t, wgt, acc[c]);
+    }
+}
+
 template <typename T, typename OT>
 __global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
     const int DV = p.D >> 2;
@@ -160,11 +191,16 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     if constexpr (KS > 0) {
         // tap q's (offset_w, offset_h, weight) from its owner lane q of this 16-lane row: DPP row_share, no LDS crossbar
 #define GP_ROWSHARE(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
+        const float Hf = (float)p.H, Wf = (float)p.W;
+        const T* imb = reinterpret_cast<const T*>(p.in) + (long)__builtin_amdgcn_readfirstlane(b) * p.H * p.W * 256;   // image base: wave-uniform
         auto tap = [&](float tw, float th, float wgt, int i, int j) {
-            const float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
-            const float loc_h = p0_h_ + (j * p.dil + th) * p.os;
-            if (loc_h > -1.f && loc_w > -1.f && loc_h < (float)p.H && loc_w < (float)p.W)
-                bilinear4<T>(im, p.H, p.W, 256, loc_h, loc_w, wgt, acc);
+            float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
+            float loc_h = p0_h_ + (j * p.dil + th) * p.os;
+            // a tap outside (-1, H) x (-1, W) contributes nothing (:258): weight zero at a harmless location
+            const bool in = loc_h > -1.f && loc_w > -1.f && loc_h < Hf && loc_w < Wf;
+            loc_w = in ? loc_w : 0.f;
+            loc_h = in ? loc_h : 0.f;
+            bilinear4_nb<T>(imb, (unsigned)lane * 4u, p.H, p.W, Hf, Wf, loc_h, loc_w, in ? wgt : 0.f, acc);
         };
         static_assert(KS == 3, "row_share immediates are spelled out for 3x3");
         tap(GP_ROWSHARE(ow, 0), GP_ROWSHARE(oh, 0), GP_ROWSHARE(mk, 0), 0, 0);
