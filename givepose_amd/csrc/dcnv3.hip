@@ -189,30 +189,62 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * 256 + lane * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KS > 0) {
-        // tap q's (offset_w, offset_h, weight) from its owner lane q of this 16-lane row: DPP row_share, no LDS crossbar
-#define GP_ROWSHARE(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
+        // Lane t < 9 of every 16-lane row owns tap t of its group and works out ONCE what all 16 lanes of the row need
+        // for that tap -- corner weights (zero for an out-of-range corner or tap), the mask weight, the byte offset of
+        // the top-left corner and the steps to the right / lower corner -- ; the tap loop then only broadcasts those
+        // eight numbers (DPP row_share, no LDS crossbar) and does the four loads + 20 FMAs.  The first version
+        // repeated the ~70 instructions of coordinate arithmetic per tap in every lane: 1 100 VALU instructions per
+        // output pixel, which is what bounded the kernel (ablation: 58 of 120 us with every load removed).
+        static_assert(KS == 3, "row_share immediates are spelled out for 3x3");
         const float Hf = (float)p.H, Wf = (float)p.W;
-        const T* imb = reinterpret_cast<const T*>(p.in) + (long)__builtin_amdgcn_readfirstlane(b) * p.H * p.W * 256;   // image base: wave-uniform
-        auto tap = [&](float tw, float th, float wgt, int i, int j) {
-            float loc_w = p0_w_ + (i * p.dil + tw) * p.os;
-            float loc_h = p0_h_ + (j * p.dil + th) * p.os;
-            // a tap outside (-1, H) x (-1, W) contributes nothing (:258): weight zero at a harmless location
-            const bool in = loc_h > -1.f && loc_w > -1.f && loc_h < Hf && loc_w < Wf;
+        const char* imb = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) +
+                                                        (long)__builtin_amdgcn_readfirstlane(b) * p.H * p.W * 256);
+        float w1, w2, w3, w4;
+        unsigned o00, dx, dy;
+        {
+            const int i = t / 3, j = t - i * 3;            // tap order: kernel_w outer, kernel_h inner
+            float loc_w = p0_w_ + (i * p.dil + ow) * p.os;
+            float loc_h = p0_h_ + (j * p.dil + oh) * p.os;
+            const bool in = t < 9 && loc_h > -1.f && loc_w > -1.f && loc_h < Hf && loc_w < Wf;
             loc_w = in ? loc_w : 0.f;
             loc_h = in ? loc_h : 0.f;
-            bilinear4_nb<T>(imb, (unsigned)lane * 4u, p.H, p.W, Hf, Wf, loc_h, loc_w, in ? wgt : 0.f, acc);
-        };
-        static_assert(KS == 3, "row_share immediates are spelled out for 3x3");
-        tap(GP_ROWSHARE(ow, 0), GP_ROWSHARE(oh, 0), GP_ROWSHARE(mk, 0), 0, 0);
-        tap(GP_ROWSHARE(ow, 1), GP_ROWSHARE(oh, 1), GP_ROWSHARE(mk, 1), 0, 1);
-        tap(GP_ROWSHARE(ow, 2), GP_ROWSHARE(oh, 2), GP_ROWSHARE(mk, 2), 0, 2);
-        tap(GP_ROWSHARE(ow, 3), GP_ROWSHARE(oh, 3), GP_ROWSHARE(mk, 3), 1, 0);
-        tap(GP_ROWSHARE(ow, 4), GP_ROWSHARE(oh, 4), GP_ROWSHARE(mk, 4), 1, 1);
-        tap(GP_ROWSHARE(ow, 5), GP_ROWSHARE(oh, 5), GP_ROWSHARE(mk, 5), 1, 2);
-        tap(GP_ROWSHARE(ow, 6), GP_ROWSHARE(oh, 6), GP_ROWSHARE(mk, 6), 2, 0);
-        tap(GP_ROWSHARE(ow, 7), GP_ROWSHARE(oh, 7), GP_ROWSHARE(mk, 7), 2, 1);
-        tap(GP_ROWSHARE(ow, 8), GP_ROWSHARE(oh, 8), GP_ROWSHARE(mk, 8), 2, 2);
-#undef GP_ROWSHARE
+            mk = in ? mk : 0.f;
+            const float fh = floorf(loc_h), fw = floorf(loc_w);
+            const float lh = loc_h - fh, lw = loc_w - fw, hh = 1.f - lh, hw = 1.f - lw;
+            const int h_low = (int)fh, w_low = (int)fw, h_high = h_low + 1, w_high = w_low + 1;
+            const bool hl = h_low >= 0, hhi = h_high <= p.H - 1, wl = w_low >= 0, whi = w_high <= p.W - 1;
+            w1 = (hl && wl) ? hh * hw : 0.f;
+            w2 = (hl && whi) ? hh * lw : 0.f;
+            w3 = (hhi && wl) ? lh * hw : 0.f;
+            w4 = (hhi && whi) ? lh * lw : 0.f;
+            const int y0 = max(h_low, 0), y1 = min(h_high, p.H - 1), x0 = max(w_low, 0), x1 = min(w_high, p.W - 1);
+            o00 = (unsigned)((y0 * p.W + x0) * 256) * (unsigned)sizeof(T);
+            dx = (unsigned)((x1 - x0) * 256) * (unsigned)sizeof(T);
+            dy = (unsigned)((y1 - y0) * p.W * 256) * (unsigned)sizeof(T);
+        }
+        const unsigned lo = (unsigned)lane * 4u * (unsigned)sizeof(T);
+#define GP_RSF(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
+#define GP_RSU(v, q) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (q), 0xF, 0xF, false)
+#define GP_TAP(q)                                                                                              \
+        {                                                                                                      \
+            const float a1 = GP_RSF(w1, q), a2 = GP_RSF(w2, q), a3 = GP_RSF(w3, q), a4 = GP_RSF(w4, q), wg = GP_RSF(mk, q); \
+            const unsigned b00 = GP_RSU(o00, q) + lo, ex = GP_RSU(dx, q), ey = GP_RSU(dy, q);                  \
+            const Ch4<T> v1 = ld4(reinterpret_cast<const T*>(imb + (size_t)b00)),                              \
+                         v2 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ex))),                       \
+                         v3 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ey))),                       \
+                         v4 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ex + ey)));                  \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+                float tt = a1 * v1.get(c);                                                                     \
+                tt = fmaf(a2, v2.get(c), tt);                                                                  \
+                tt = fmaf(a3, v3.get(c), tt);                                                                  \
+                tt = fmaf(a4, v4.get(c), tt);                                                                  \
+                acc[c] = fmaf(tt, wg, acc[c]);                                                                 \
+            }                                                                                                  \
+        }
+        GP_TAP(0) GP_TAP(1) GP_TAP(2) GP_TAP(3) GP_TAP(4) GP_TAP(5) GP_TAP(6) GP_TAP(7) GP_TAP(8)
+#undef GP_TAP
+#undef GP_RSU
+#undef GP_RSF
     } else {
         int q = 0;
         for (int i = 0; i < p.K; ++i)
