@@ -1111,6 +1111,12 @@ static bool conv_window_enabled() {   // A/B switch: GP_CONV_WINDOW=0 keeps 3x3 
     return on;
 }
 
+static long pp_min_k() {   // shortest K that goes to the ping-pong kernel when batches overlap (GP_PP_MIN_K, default 512);
+                           // twice that for a launch that runs alone: measured end to end, bs 64 (K = 512: stage-2 fc1)
+    static const long k = [] { const char* e = getenv("GP_PP_MIN_K"); return e ? atol(e) : 512l; }();
+    return k;
+}
+
 static long pp_min_tiles() {
     const char* e = getenv("GP_GEMM_PP_MIN_TILES");
     return e ? atol(e) : 192;
@@ -1194,7 +1200,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // co_scheduled (several batches in flight: PoseNet(inflight > 1)): a launch need not fill the chip by itself,
             // the 256x256 ping-pong tile is then the cheapest per FLOP even for 32-128 tiles (GP_GEMM_PP_MIN_TILES: A/B)
             const bool fills = tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU;
-            if (d->N % 256 == 0 && d->K >= 512 && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
         else variant = 4;
