@@ -1217,12 +1217,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
         p.tiles_m = d->M / 256;
         p.tiles_n = 1;
-        // 4-stage W ring, DMA lead 2 (the 5-stage / lead-3 instantiation measured 1.6x slower: dbg 7 keeps it for A/B)
-        if (p.dbg == 7) {
-            if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
-            else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((conv3_pp_kernel<16, 5>), dim3(p.tiles_m), dim3(512), 0, s, p);
-        } else if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        // 4-stage W ring, DMA lead 2 (a 5-stage / lead-3 instantiation spilled 43 registers and ran 1.6x slower)
+        if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3_pp_kernel<16, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         GP_LAUNCH_CHECK("gp_gemm");
