@@ -26,6 +26,15 @@ elif mode == "v1nosplit":      # the split-K sites run the register-staged 128x1
 elif mode == "cap4":
     ops.auto_splitk = lambda M, N, K, esz, n_cu=256: min(4, _orig(M, N, K, esz))
 net = PoseNet(PoseNetConfig(fuse_mlp=not os.environ.get("NOFUSE")), dtype=torch.float16, seed=0, use_graph=True, inflight=NS).cuda()
+if mode == "forcesplit":        # automatic split-K (two-kernel path on gemm_kernel) although batches overlap
+    def _la(B_, plan, _seq=net._launch_seq):
+        prev = ops.AUTO_SPLITK, ops.CO_SCHEDULED
+        ops.AUTO_SPLITK, ops.CO_SCHEDULED = True, True
+        try:
+            _seq(B_, plan)
+        finally:
+            ops.AUTO_SPLITK, ops.CO_SCHEDULED = prev
+    net._launch_all = _la
 d = [batch(21 + i) for i in range(NS)]
 skip = ("h0", "h1", "e_in0", "e_in1", "e_in2", "gn_partial")
 ref = []
