@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgivepose_hip.so")
+# GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
+LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
 GP_F32, GP_F16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3

@@ -2,17 +2,16 @@
 //
 //   C[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] )
 //
-// Tile 128 (m) x 128 (n) x 128 bytes of K per step, 4 waves (2 m x 2 n), each wave 64x64 as 4x4
-// MFMA 16x16 tiles.  W rows are the MFMA "A" operand and X rows the "B" operand, so a lane's four
-// accumulator registers are four consecutive n of one m: the epilogue stores 8 B (f16) / 16 B (f32)
-// contiguous per lane straight from registers.  Both operands are staged through LDS as
-// [row][128 B] with a 16-byte-chunk XOR swizzle (chunk ^= row & 7) that makes the ds_read_b128
-// fragment reads bank-conflict free (lane groups of 16 hit 16 distinct 16-B slots).  Global->LDS is
-// register staged and double buffered: tile t+1 is in flight while tile t is multiplied, one
-// barrier per K step.  In conv mode the X loader walks (kh,kw,ci) in K order and zero-fills the
-// padding, so no im2col buffer ever exists in HBM.  Workgroup ids are remapped so that each XCD
-// (ids equal mod 8 share one) owns a contiguous run of tiles with n fastest: the X panel of an
-// m-tile is fetched into one XCD's L2 once and reused by all its n-tiles.
+// All kernels below stage both operands through LDS with LDS-DMA (global_load_lds_dwordx4) as [row][RB bytes] with a
+// 16-byte-chunk XOR swizzle applied on the SOURCE address, so that the ds_read_b128 fragment reads are bank-conflict
+// free.  W rows are the MFMA "A" operand and X rows the "B" operand, so a lane's four accumulator registers are four
+// consecutive n of one m.  In conv mode the X loader walks (kh,kw,ci) in K order and takes padding from a zero page,
+// so no im2col buffer ever exists in HBM.  Workgroup ids are remapped so that each XCD (ids equal mod 8 share one)
+// owns a contiguous run of tiles with n fastest: the X panel of an m-tile is fetched into one XCD's L2 once.
+// Split-K (skinny GEMMs: M = 64 rows of the PnP fc layers) runs on the 128x128 LDS-DMA tile with fp32 partial slabs
+// and a reduce kernel that applies the epilogue.  The round-1 register-staged 128x128 kernel is gone: its
+// compiler-scheduled ds_read_b128 + MFMA loop corrupted packed-fp32 VALU results of OTHER kernels' waves resident on
+// the same SIMD (two-stream reproducer scripts/race_min.py).
 //
 // dtype f16: v_mfma_f32_16x16x32_f16 (8 halfs = one 16-B chunk per lane per MFMA).
 // dtype f32: v_mfma_f32_16x16x4_f32 x4 per 16-B chunk (exact fp32 products, fp32 accumulate); the
@@ -147,174 +146,6 @@ template <> __device__ __forceinline__ void mma<float>(f32x4& acc, const uint4& 
     const float* bf = reinterpret_cast<const float*>(&b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmKP p) {
-    constexpr int EPT = 16 / sizeof(T);   // elements per 16-byte chunk
-    constexpr int KPT = 128 / sizeof(T);  // K elements per step
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-
-    // XCD-chunked, bijective tile remap (ids equal mod 8 share an XCD)
-    const int nblk = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * 128, n0 = tn * 128;
-    const int kt_begin = blockIdx.y * p.kt_per_split;
-    const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);
-
-    const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
-    const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
-
-    // ---- loader state: thread owns 16-B chunk `lc` of rows lr, lr+32, lr+64, lr+96 of both tiles
-    const int lc = tid & 7, lr = tid >> 3;
-    long xbase[4];
-    int hi0[4], wi0[4];
-    bool xok[4], wok[4];
-    const T* wrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lr + 32 * i;
-        xok[i] = m < p.M;
-        if (p.conv) {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, r = m - b * hw;
-            const int ho = r / p.Wo, wo = r - ho * p.Wo;
-            hi0[i] = ho * p.stride - p.pad;
-            wi0[i] = wo * p.stride - p.pad;
-            xbase[i] = (long)b * p.H * p.Win;
-        } else {
-            hi0[i] = wi0[i] = 0;
-            xbase[i] = (long)m * p.ldx + lc * EPT;
-        }
-        const int n = n0 + lr + 32 * i;
-        wok[i] = n < p.N;
-        wrow[i] = W + (long)n * p.K + lc * EPT;
-    }
-    const int cpt = p.conv ? p.Cin / KPT : 1;  // k-steps per filter tap
-
-    uint4 xr[4], wr[4];
-    auto gload = [&](int kt) {
-        int kh = 0, kw = 0, ci = 0;
-        if (p.conv) {
-            const int tap = kt / cpt;
-            ci = (kt - tap * cpt) * KPT + lc * EPT;
-            kh = tap / p.KW;
-            kw = tap - kh * p.KW;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (p.conv) {
-                const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-                if (xok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.Win)
-                    v = *reinterpret_cast<const uint4*>(X + (xbase[i] + (long)hi * p.Win + wi) * p.Cin + ci);
-            } else if (xok[i]) {
-                v = *reinterpret_cast<const uint4*>(X + xbase[i] + (long)kt * KPT);
-            }
-            xr[i] = v;
-            wr[i] = wok[i] ? *reinterpret_cast<const uint4*>(wrow[i] + (long)kt * KPT) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    const int soff = lr * 128 + ((lc ^ (lr & 7)) << 4);
-    auto sstore = [&](int buf) {
-        char* xs = smem + buf * 32768;
-        char* ws = xs + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(xs + soff + i * 4096) = xr[i];
-            *reinterpret_cast<uint4*>(ws + soff + i * 4096) = wr[i];
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int xfo = (wm * 64 + fr) * 128, wfo = (wn * 64 + fr) * 128, sw = fr & 7;
-    auto compute = [&](int buf) {
-        const char* xs = smem + buf * 32768;
-        const char* ws = xs + 16384;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 4 + fq) ^ sw) << 4;
-            uint4 xf[4], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xf[t] = *reinterpret_cast<const uint4*>(xs + xfo + t * 2048 + co);
-                wf[t] = *reinterpret_cast<const uint4*>(ws + wfo + t * 2048 + co);
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
-        }
-    };
-
-    if (kt_begin < kt_end) {
-        gload(kt_begin);
-        sstore(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) gload(kt + 1);
-        compute(buf);
-        if (more) sstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    // ---- epilogue straight from registers: lane holds C[m][n..n+3]; all loads before the first store
-    if (p.splitk > 1) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wm * 64 + mt * 16 + fr;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-                if (n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((long)blockIdx.y * p.M + m) * p.N + n) = acc[nt][mt];
-            }
-        }
-        return;
-    }
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 b4[4], g4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-        b4[nt] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
-        g4[nt] = (p.epi == GP_EPI_SCALE_RES && n < p.N) ? *reinterpret_cast<const f32x4*>(p.gamma + n) : zero4;
-    }
-    typename Res4<T>::type r4[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int m = m0 + wm * 64 + mt * 16 + fr, n = n0 + wn * 64 + nt * 16 + fq * 4;
-            for (int j = 0; j < 4; ++j) r4[mt][nt][j] = 0;
-            if ((p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) && m < p.M && n < p.N) r4[mt][nt] = load_res4<T>(p, m, n);
-        }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            if (n < p.N) store4<T>(p, m, n, epi_apply<T>(p.epi, acc[nt][mt], b4[nt], g4[nt], r4[mt][nt]));
-        }
-    }
 }
 
 template <typename T>
@@ -487,8 +318,19 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP pin) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
+    // split-K (generic ring schedule only): workgroup row blockIdx.y multiplies K steps [kt0, kt0 + nkt) into its own
+    // fp32 slab of the workspace; the host passes C = workspace, out_f32, no bias / epilogue (splitk_reduce_kernel applies them)
+    GemmKP p = pin;
+    int kt0 = 0;
+    if constexpr (!PP && !(DB && NS == 2)) {
+        if (pin.splitk > 1) {
+            kt0 = blockIdx.y * pin.kt_per_split;
+            p.nkt = min(pin.nkt - kt0, pin.kt_per_split);
+            p.C = reinterpret_cast<float*>(pin.C) + (long)blockIdx.y * pin.M * pin.N;
+        }
+    }
     static_assert(!PP || (WM * WN == 8 && (NS == 4 || NS == 5) && RB == 64 && !DB), "ping-pong schedule: 8 waves, 4/5-stage ring of 64-byte K steps");
     constexpr int NW = WM * WN;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -561,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         const unsigned ws = xs + BM * RB;
         long xoff;      // wave-uniform byte offset of this K step from the row base pointer
         unsigned bit = 1u;
+        kt += kt0;
         if (p.conv) {
             const int tap = kt / cpt;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -1007,17 +850,24 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
-    // LDS byte address of this lane's B fragment per m-tile and kw (tap row kh adds kh * WW * 64 as an immediate)
-    unsigned xa[MT][3];
+    // LDS byte address of this lane's B fragment per m-tile for kw = 0; tap (kh, kw) adds the lane constant xd[kw] and
+    // kh * WW * 64 as an immediate.  xd does not depend on the m-tile: the window pixel index of (mt, fr) is
+    // pb = (ml / WIMG) * WW + ml % WIMG with ml = wm * 128 + mt * 16 + fr, and WW, 16 and WIMG are multiples of 8, so
+    // pb % 8 == fr % 8 for every mt -- and the swizzle term only looks at bit 2 of the pixel index.  (One address per
+    // (mt, kw) cost 24 registers and made hipcc spill: scratch is banned on the path)
+    unsigned xa[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int ml = wm * 128 + mt * 16 + fr;
         const int pb = (ml / WIMG) * WW + (ml % WIMG);
+        xa[mt] = WIN0 + pb * 64 + ((fq ^ (((pb >> 2) & 1) << 1)) << 4);   // offset into smem
+    }
+    static_assert(WW % 8 == 0 && WIMG % 8 == 0, "the kw deltas must not depend on the m-tile");
+    unsigned xd[3];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int px = pb + kw;
-            xa[mt][kw] = WIN0 + px * 64 + ((fq ^ (((px >> 2) & 1) << 1)) << 4);   // offset into smem
-        }
+    for (int kw = 0; kw < 3; ++kw) {
+        const int p0 = fr & 7, p1 = p0 + kw;
+        xd[kw] = kw * 64 + (((fq ^ (((p1 >> 2) & 1) << 1)) - (fq ^ (((p0 >> 2) & 1) << 1))) << 4);
     }
     const int wfo = (wn * 64 + fr) * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
 
@@ -1040,9 +890,11 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             const char* ws = smem + rbuf * WST + wfo;
 #pragma unroll
             for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const uint4*>(ws + t * 1024);
+            unsigned xdk = xd[kw];
+            asm volatile("" : "+v"(xdk));   // opaque per tap: keeps hipcc from hoisting xa + xd into 24 loop-invariant registers
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                xf[mt] = *reinterpret_cast<const uint4*>(smem + xa[mt][kw] + kh * WW * 64);
+                xf[mt] = *reinterpret_cast<const uint4*>(smem + (xa[mt] + xdk) + kh * WW * 64);
             __builtin_amdgcn_sched_barrier(0);
             // DMA: one window piece of the NEXT chunk during taps 1..4 (its buffer was last read in chunk cc - 1, whose
             // reads are two barriers back by tap 1), then the W rows of step st + 2; then wait for the own W of st + 1
@@ -1075,9 +927,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) xa[mt][kw] += (cc & 1) ? -WINB : WINB;     // the other window buffer
+        for (int mt = 0; mt < MT; ++mt) xa[mt] += (cc & 1) ? -WINB : WINB;     // the other window buffer
     }
     if (!grp) __builtin_amdgcn_s_barrier();
 
@@ -1095,7 +945,16 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
     p.nkt = p.K / (RB / (int)sizeof(T));
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, s, p);
+    int splits = 1;
+    if constexpr (!PP && !(DB && NS == 2)) {   // split-K: blockIdx.y walks the K ranges (generic ring schedule only)
+        if (p.splitk > 1) {
+            if (p.splitk > p.nkt) p.splitk = p.nkt;
+            p.kt_per_split = cdiv(p.nkt, p.splitk);
+            p.splitk = cdiv(p.nkt, p.kt_per_split);
+            splits = p.splitk;
+        }
+    }
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -1172,13 +1031,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     } else {
         GP_REQUIRE(d->ldx >= d->K && d->ldx % (16 / esz) == 0, "gp_gemm: ldx=%d invalid", d->ldx);
     }
-    p.tiles_m = cdiv(d->M, 128);
-    p.tiles_n = cdiv(d->N, 128);
-    p.nkt = d->K / KPT;
     p.splitk = d->splitk > 1 ? d->splitk : 1;
-    if (p.splitk > p.nkt) p.splitk = p.nkt;
-    p.kt_per_split = cdiv(p.nkt, p.splitk);
-    p.splitk = cdiv(p.nkt, p.kt_per_split);
+    if (p.splitk > d->K / KPT) p.splitk = d->K / KPT;
     if (p.splitk > 1) GP_REQUIRE(d->workspace != nullptr, "gp_gemm: splitk needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * d->N * d->K;
@@ -1186,16 +1040,16 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     const double bytes = xbytes + (double)d->N * d->K * esz + (double)d->M * d->N * (d->out_f32 ? 4 : esz) +
                          (d->epilogue >= GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
-    // variant: 1 = 128x128 register-staged (+split-K), 2 = 256x128 LDS-DMA, 3 = 256x256 LDS-DMA, 0 = pick
+    // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
     if (variant == 0) {
         // measured per shape (scripts/gemm_bench.py): where 256x256 tiles fill the chip (N % 256 == 0, >= 192 tiles)
         // the ping-pong kernel (10) for K >= 512 and the 256x128 tile at two workgroups per CU (8) for shorter K
         // (its epilogues overlap the other workgroup's main loop); otherwise
-        // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K stays on the register-staged kernel
+        // 128x128 at two workgroups per CU (7); fp32 storage: 128x128 (4); split-K: 128x128 (4) + reduce kernel
         const long tA = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
-        if (p.splitk > 1) variant = 1;
+        if (p.splitk > 1) variant = 4;
         else if (d->dtype == GP_F16) {
             // co_scheduled (several batches in flight: PoseNet(inflight > 1)): a launch need not fill the chip by itself,
             // the 256x256 ping-pong tile is then the cheapest per FLOP even for 32-128 tiles (GP_GEMM_PP_MIN_TILES: A/B)
@@ -1212,7 +1066,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         !d->out_f32 && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
-    GP_REQUIRE(variant >= 1 && variant <= 13 && (variant == 1 || p.splitk == 1), "gp_gemm: bad variant %d", variant);
+    GP_REQUIRE(variant >= 2 && variant <= 13 && variant != 6 && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     if (variant == 13) {
         GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
         p.tiles_m = d->M / 256;
@@ -1224,11 +1078,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 12) {   // as 10 with a 5-stage ring (all 160 KB of LDS), DMA lead 3
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 5, false, 64, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 5, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 10) {   // 256x256 ping-pong: 8 waves of 128x64, 64-byte K steps, 4-stage ring, one workgroup per CU
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 11) {   // 128x256 ping-pong: 8 waves of 64x64
@@ -1237,16 +1091,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     }
     if (variant == 8) {   // 256x128, 4 waves of 128x64, 64-byte K steps, 3-stage ring: two workgroups per CU, so the
                           // epilogue of one overlaps the main loop of the other (short-K, store-heavy shapes)
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 9) {   // 128x128, 64-byte K steps, 4-stage ring, two workgroups per CU
         if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 4, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);   // experiment: as 8 with 4 stages = 96 KB LDS = one workgroup per CU
-        GP_LAUNCH_CHECK("gp_gemm");
-    }
-    GP_REQUIRE(!(p.gn_partial && variant == 1), "gp_gemm: fused GroupNorm needs a large-tile variant");
-    if (variant == 6) {   // A/B arms: explicit fragment double buffering (f16 only; fp32 falls back to 3 / 4)
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2, true>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 7) {
@@ -1258,28 +1107,27 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 4) {
+        if (p.splitk > 1) {
+            // main kernel: raw fp32 partial sums, slab blockIdx.y of the workspace; then the reduce kernel with the real epilogue
+            GemmKP q = p;
+            q.C = d->workspace; q.out_f32 = 1; q.ldc = d->N; q.epi = GP_EPI_NONE; q.bias = nullptr; q.gamma = nullptr; q.res = nullptr;
+            if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(q, s); else launch_big<float, 2, 2, 4, 4, 2>(q, s);
+            p.splitk = q.splitk;      // >= 2: the request was clamped to the number of K steps above
+            const long work = (long)d->M * (d->N / 4);
+            if (d->dtype == GP_F16) hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
+            GP_LAUNCH_CHECK("gp_gemm");
+        }
         if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 3) {
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2>(p, s); else launch_big<float, 2, 4, 8, 4, 2>(p, s);
+        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 2>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 2) {
         if (d->dtype == GP_F16) launch_big<half_t, 4, 2, 4, 4, 3>(p, s); else launch_big<float, 4, 2, 4, 4, 3>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
-    dim3 grid(p.tiles_m * p.tiles_n, p.splitk);
-    if (d->dtype == GP_F16)
-        hipLaunchKernelGGL(gemm_kernel<half_t>, grid, dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL(gemm_kernel<float>, grid, dim3(256), 0, s, p);
-    if (p.splitk > 1) {
-        const long work = (long)d->M * (d->N / 4);
-        if (d->dtype == GP_F16)
-            hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
-    }
-    GP_LAUNCH_CHECK("gp_gemm");
+    return gp_fail(GP_ERR_INVALID, "gp_gemm: variant %d not handled", variant);
 }

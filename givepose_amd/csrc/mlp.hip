@@ -130,7 +130,8 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
 
         // ---- fragment reads of the whole chunk up front (hipcc otherwise re-uses ONE fragment register set and waits
         //      lgkmcnt(0) in front of every MFMA pair); W2's land under GEMM1 and the GELU
-        constexpr int GK = KS > 4 ? 2 : KS;          // k-steps of W1 fragments resident at a time (register budget)
+        constexpr int GK = KS > 4 ? 1 : KS;          // k-steps of W1 fragments resident at a time (register budget: C = 256 must
+                                                     // not spill -- no kernel of the path may use scratch)
         f32x4 acc1[2][MT];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
                     for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = mma16(a1[ks][nt], xf[mt][k0 + ks], acc1[nt][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        constexpr int GC = CT > 8 ? 4 : CT;          // W2 fragments resident at a time
+        constexpr int GC = CT > 8 ? 2 : CT;          // W2 fragments resident at a time
         uint4 a2[GC];
 #pragma unroll
         for (int ct = 0; ct < GC; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + ct * 1024);
@@ -212,9 +213,14 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
     // ---- epilogue
     constexpr int LPR = ROWB / 16, RPS = 64 / LPR, NIT = 32 / RPS;   // lanes per row, rows per store instruction
     const int rr = lane / LPR, rc = lane % LPR;
+    // C = 128: the residual rows are requested before the transpose (their latency hides under it).  C = 256: 64
+    // registers of residual beside the 128 accumulators would spill, so they are requested once the accumulators are
+    // in the slab (the other wave of the SIMD covers the latency); no kernel of the path may use scratch
     half8 rres[NIT];
+    if constexpr (C == 128) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
+        for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
+    }
     char* slab = smem + wave * SLAB;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -226,6 +232,11 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
             for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
             *reinterpret_cast<half4*>(slab + (mt * 16 + fr) * PITCH + (ct * 4 + fq) * 8) = o;
         }
+    }
+    if constexpr (C != 128) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {

@@ -943,8 +943,7 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
             if (nslab == 1) launch_dw7_tiled<half_t, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
             else if (nslab == 2) launch_dw7_tiled<half_t, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
             else if (nslab == 4) launch_dw7_tiled<half_t, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-            else if (nslab == 8) launch_dw7_tiled<half_t, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-            else done = false;
+            else done = false;   // C = 1024 in fp16: the 8-slab instantiation spilled to scratch (banned) -> strip kernel
         } else {
             if (nslab == 2) launch_dw7_tiled<float, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
             else if (nslab == 4) launch_dw7_tiled<float, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);

@@ -68,9 +68,9 @@ def _workspace(device, nfloats):
     return ws
 
 
-# Automatic split-K (skinny GEMMs: the PnP fc layers, feat_reducer) is switched off by PoseNet when several batches are
-# in flight: the two-kernel split-K path is then not needed for occupancy (another batch fills the chip) and, run
-# beside another batch's launches, it was the one ingredient of timing-dependent results on MI355X.
+# Automatic split-K for skinny GEMMs (the PnP fc layers, feat_reducer): 128x128 LDS-DMA tiles + a reduce kernel.
+# (Round 1 ran split-K on a register-staged kernel whose MFMA loop corrupted packed-fp32 results of OTHER kernels' waves
+# on the same SIMD when batches overlapped -- that kernel is gone)
 AUTO_SPLITK = True
 # set beside it: tells gp_gemm that other launches run next to this one (tile chosen per FLOP, not to fill the chip)
 CO_SCHEDULED = False
@@ -113,7 +113,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 1) and gn is None and ln is None) else 1
+        splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 4) and gn is None and ln is None) else 1
     d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None

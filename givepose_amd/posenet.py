@@ -70,7 +70,7 @@ class PoseNet(nn.Module):
                 aliases[key] = t
             _register(self, name, t, not is_buf)
         self._packed = None       # device-side packed weights
-        self.inflight = int(inflight)   # batches the caller keeps in flight (forward_device slots); > 1 turns split-K off
+        self.inflight = int(inflight)   # batches the caller keeps in flight (forward_device slots)
         self._plans = {}          # (B, slot) -> buffers / graph
         self._streams = {}        # slot -> dedicated stream of the hipGraph path
         self.eval()
@@ -318,12 +318,12 @@ class PoseNet(nn.Module):
         return x
 
     def _launch_all(self, B, plan):
-        prev = ops.AUTO_SPLITK, ops.CO_SCHEDULED
-        ops.AUTO_SPLITK, ops.CO_SCHEDULED = self.inflight <= 1, self.inflight > 1
+        prev = ops.CO_SCHEDULED
+        ops.CO_SCHEDULED = self.inflight > 1      # tile choice only; the launch sequence is the same in both modes
         try:
             self._launch_seq(B, plan)
         finally:
-            ops.AUTO_SPLITK, ops.CO_SCHEDULED = prev
+            ops.CO_SCHEDULED = prev
 
     def _launch_seq(self, B, plan):
         W, buf, cfg = self._packed, plan["buf"], self.cfg

@@ -30,9 +30,32 @@ def test_ctypes_prototypes_cover_header():
     assert lib.gp_version() >= 100
 
 
-def test_code_object_targets_gfx950():
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH], capture_output=True, text=True)
+def _kernel_notes(tmp_path):
+    """Extract the gfx950 code objects of the library (into tmp_path: llvm-objdump writes next to its input) and
+    return {kernel name: {metadata key: int}} from their ELF notes."""
+    import shutil
+    lib = shutil.copy(_lib.LIB_PATH, tmp_path / "lib.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(lib)], capture_output=True, text=True)
     assert "gfx950" in out.stdout + out.stderr
+    kernels = {}
+    for f in sorted(tmp_path.glob("lib.so.*gfx950")):
+        notes = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(f)], text=True)
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            kernels[name] = {k: int(v) for k, v in re.findall(r"\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|"
+                                                              r"group_segment_fixed_size|vgpr_count):\s+(\d+)", blk)}
+    return kernels
+
+
+def test_code_object_targets_gfx950_and_no_kernel_uses_scratch(tmp_path):
+    """Every kernel of the library must fit its registers: a kernel with a private (scratch) segment is banned from
+    the product (DESIGN.md 6b -- spilled kernels on concurrent streams were the ingredient of the round-1 in-flight
+    corruption, and compiler-issued scratch traffic sits inside hand-counted vmcnt windows)."""
+    kernels = _kernel_notes(tmp_path)
+    assert len(kernels) > 50, sorted(kernels)
+    bad = {n: k for n, k in kernels.items() if k["private_segment_fixed_size"] or k["vgpr_spill_count"] or k["sgpr_spill_count"]}
+    assert not bad, bad
+    assert all(k["group_segment_fixed_size"] <= 160 * 1024 for k in kernels.values())
 
 
 def test_product_never_imports_oracle():
