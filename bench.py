@@ -9,18 +9,28 @@ ConvPnPNet, pose decode) over one batch of 64 synthetic 256x256 crops per GPU, i
 storage / fp32 accumulate, random-init (seeded) weights; for N > 1 each rank owns its own 64 crops (weak
 scaling) and the step ends with the RCCL all-gather of the per-crop (R,t,s).  Rank 0 prints ONE JSON line.
 
+`value` is measured with `--inflight` (default 3) independent batches in flight per GPU (givepose_amd.runner); the
+strictly serial rate of a separately built `PoseNet(inflight=1)` is reported beside it (`one_batch_in_flight`).
+
 Extra objects on the line:
-  roofline     -- dominant kernel (MFMA GEMM / implicit-GEMM conv): algorithmic FLOP per launch / average launch
-                  duration, measured with hipEvents around every launch of a separate eager pass on the launch
-                  stream (hipGraph replay of the timed region cannot carry per-kernel events); kernel_classes has
-                  the same for every kernel class, incl. the DCNv3 gather against the HBM roofline.
-  cpu_baseline -- the oracle (oracle/posenet_ref.py, fp32 PyTorch-CPU restatement of the reference) timed on this
-                  box's host cores on a bounded sample (rank 0, N = 1 only).
+  roofline     -- dominant kernel class (MFMA GEMM / implicit-GEMM conv / fused MLP): algorithmic FLOP (as the C ABI
+                  counts them per launch) / launch duration, hipEvents around every launch of a separate eager pass
+                  of the serial net on the launch stream; `kernels` = the three most expensive kernels (label + shape)
+                  with their own fractions; kernel_classes has every class incl. the DCNv3 gather (HBM roofline).
+                  `traffic` = HBM bytes per launch from rocprofv3 PMC passes committed under profiles/ (tagged with
+                  the commit they were taken on), null when no matching profile exists.
+  parity_mode  -- the same step in fp32 storage (the mode that meets the 1e-4 bar of north_star): images/s and the
+                  largest |fast - parity| difference of R / t / s on this batch (both are HIP paths; the error of each
+                  mode against the reference is asserted in tests/test_hip_posenet.py and quoted in `vs_reference`).
+  cpu_baseline -- the oracle (oracle/posenet_ref.py, fp32 PyTorch-CPU restatement of the reference) on the host
+                  cores: median of B=64 and B=1 passes on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,31 +40,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_CROP = {"full": 67.517, "nodcn": 66.506, "resnet34": 36.81, "resnet34_nodcn": 35.80, "att": 66.43}
-GATHER_MB_PER_CROP = 3.74
 PEAK_F16_TFLOPS = 2500.0                                 # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3                                  # fp32 MFMA
 PEAK_HBM_GBS = 8000.0
+# measured against the reference golden vectors / the oracle in tests/test_hip_posenet.py (max abs error, B in {1,4,5,64})
+VS_REFERENCE = {"f32": {"rot": 4e-5, "trans": 5e-6, "size": 1.3e-5, "meets_1e-4": True},
+                "f16": {"rot": 1.5e-2, "trans": 1.6e-3, "size": 1.1e-2, "meets_1e-4": False,
+                        "note": "fp16 operands cannot meet 1e-4: rounding the weights alone gives 1.5e-3 (tests/precision_model.py)"}}
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota (a GPU box hands a container its share of
+    a large host -- oversubscribing the quota makes the CPU baseline many times slower), capped at 32 threads."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def note(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def timed(fn, steps, fence, world, dev):
+    import torch.distributed as dist
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    return dt
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--workload", default="full", choices=["full", "nodcn", "resnet34", "resnet34_nodcn", "att"],
-                    help="full = reference wiring (ConvNeXt-B + DCNv3, BASELINE configs[2]); nodcn = use_dcn=''; "
-                         "resnet34[_nodcn] = BASELINE configs[0-1] read literally (ResNet-34 trunk, not wired by the reference)")
+                    help="full = reference wiring (ConvNeXt-B + DCNv3, BASELINE configs[2]); nodcn = use_dcn='' (configs[1]); "
+                         "att = MAPTransformerEncoer (configs[3] analogue); resnet34[_nodcn] = ResNet-34 trunk variant")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches in flight per GPU (PoseNet slots: own buffers / hipGraph / stream, shared "
                          "weights); 1 = strictly one step after the other")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true")
     args = ap.parse_args()
 
+    try:        # before anything touches the GPU (the .git directory does not travel to the GPU box: usually absent there)
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        commit = None
     from givepose_amd import PoseNet, PoseNetConfig, _lib, synth
     from givepose_amd import dist as gd
+    from givepose_amd.runner import ShardRunner
     import torch.distributed as dist
 
     # GP_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (gloo backend, every rank on cuda:0);
@@ -70,31 +123,13 @@ def main():
     dtype = torch.float16 if args.dtype == "f16" else torch.float32
     cfg = PoseNetConfig(use_dcn="" if args.workload.endswith("nodcn") else "dcnv3",
                         main_backbone="resnet34" if args.workload.startswith("resnet34") else "convnext",
-                        nocsmap_encoder="att" if args.workload == "att" else "conv")   # att = BASELINE configs[3] in-repo analogue
+                        nocsmap_encoder="att" if args.workload == "att" else "conv")
     NF = 1 if args.no_graph else max(1, args.inflight)      # slots need the graph path's per-slot streams
     net = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph, inflight=NF).to(dev)
-    statics = [net.static_inputs(B, dev, slot=i) for i in range(NF)]
-    static = statics[0]
+    run = ShardRunner(net, B, dev, world)
     host = synth.synth_batch(B, seed=1000 + rank)
-    for i, st in enumerate(statics):                        # every slot holds its own batch
-        hb = host if i == 0 else synth.synth_batch(B, seed=1000 + rank + 100 * i)
-        for k, v in hb.items():
-            st[k].copy_(torch.from_numpy(v).reshape(st[k].shape))
-    poses = [torch.empty(B, gd.POSE_WIDTH, device=dev) for _ in range(NF)]
-    gathered = [torch.empty(world * B, gd.POSE_WIDTH, device=dev) for _ in range(NF)] if world > 1 else None
-    counter = [0]
-
-    def step():
-        """One pass of the path over one batch; with NF > 1 consecutive steps use different slots and overlap on the
-        device (nothing is skipped: every step runs the whole launch sequence on its own buffers)."""
-        i = counter[0] % NF
-        counter[0] += 1
-        out = net.forward_device(statics[i], dev, slot=i, wait=NF == 1)
-        if world > 1:
-            with torch.cuda.stream(net.stream(i) if NF > 1 else torch.cuda.current_stream(dev)):
-                gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses[i])
-                gd.all_gather_poses(poses[i], world, out=gathered[i])
-        return out
+    for i in range(NF):                                     # every slot holds its own batch
+        run.load(i, host if i == 0 else synth.synth_batch(B, seed=1000 + rank + 100 * i))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -103,19 +138,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(max(args.warmup, 2 * NF)):  # per slot: first call eager, graph capture on the second
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        run.step()
+    dt = timed(run.step, args.steps, fence, world, dev)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
 
     line = {
         "metric": "images/sec PoseNet fwd, bs=64 256x256 fp16, 1/2/4/8 MI355X; % MFMA roofline",
@@ -124,51 +151,51 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("PoseNet.forward: " + ("ResNet-34" if args.workload.startswith("resnet34") else "ConvNeXt-B")
                                 + " trunk + SizeHead + NOCS TopDownXyzHead + "
-                                + ("plain-conv MAPEncoder (use_dcn='')" if args.workload.endswith("nodcn") else
-                                   "MAPTransformerEncoer (64-token attention)" if args.workload == "att" else "DCNv3 MAPEncoder")
-                                + " + IVFC TopDownXyzHead + ConvPnPNet + pose decode (BASELINE configs[2]; the reference wires "
-                                  "ConvNeXt-B, not ResNet-34: SURVEY.md 0.2)"),
+                                + ("plain-conv MAPEncoder (use_dcn='', BASELINE configs[1])" if args.workload.endswith("nodcn") else
+                                   "MAPTransformerEncoer (64-token attention, configs[3] analogue)" if args.workload == "att"
+                                   else "DCNv3 MAPEncoder (BASELINE configs[2])")
+                                + " + IVFC TopDownXyzHead + ConvPnPNet + pose decode (the reference wires ConvNeXt-B, not "
+                                  "ResNet-34: SURVEY.md 0.2)"),
                    "batch_per_gpu": B, "global_batch": world * B, "img": "256x256", "parallelism": f"dp{world}",
                    "weights": "seeded random init (givepose_amd.synth, seed 0)", "hipgraph": not args.no_graph,
                    "batches_in_flight": NF,
-                   "collective": "all_gather (B,15) fp32 per rank" if world > 1 else "none"},
-        "path_roofline_frac_mfma": round(value / world * GFLOP_PER_CROP[args.workload] * 1e9 / (PEAK_F16_TFLOPS * 1e12), 4),
+                   "collective": "all_gather (B,15) fp32 per rank, one comm stream" if world > 1 else "none"},
+        "path_roofline_frac_mfma": round(value / world * GFLOP_PER_CROP[args.workload] * 1e9 / (peak * 1e12), 4),
+        "vs_reference": VS_REFERENCE[args.dtype],
     }
 
-    # the same K steps strictly one after the other (one batch in flight), for reference beside `value`
+    if rank == 0:
+        note(f"timed region: {value:.1f} images/s")
+    # ---------------- the same K steps strictly one after the other, on a net BUILT for one batch in flight
+    net1 = None
     if NF > 1:
-        def step1():
-            out = net.forward_device(statics[0], dev, slot=0, wait=True)
-            if world > 1:
-                gd.pack_poses(out["rot"], out["trans"], out["size"], out=poses[0])
-                gd.all_gather_poses(poses[0], world, out=gathered[0])
-        step1()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step1()
-        fence()
-        dt1 = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt1], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt1 = float(tt)
+        net1 = PoseNet(cfg, dtype=dtype, seed=0, use_graph=not args.no_graph, inflight=1).to(dev)
+        run1 = ShardRunner(net1, B, dev, world)
+        run1.load(0, host)
+        for _ in range(3):
+            run1.step()
+        dt1 = timed(run1.step, args.steps, fence, world, dev)
         line["one_batch_in_flight"] = {"value": round(world * B * args.steps / dt1, 2), "unit": "images/s",
                                        "ms_per_step": round(dt1 / args.steps * 1e3, 4)}
+    serial = net1 if net1 is not None else net
 
-    # ---------------- roofline leg: per-launch hipEvents on the launch stream, eager pass
+    if rank == 0:
+        note("serial leg done")
+    # ---------------- roofline leg: per-launch hipEvents on the launch stream, eager pass of the serial net
     if rank == 0 and not args.no_roofline:
         lib = _lib.load()
-        net_e = net
-        net_e.use_graph = False
+        graph_was = serial.use_graph
+        serial.use_graph = False
+        static = serial.static_inputs(B, dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         reps = 3
-        net_e.forward_device(static, dev)
+        serial.forward_device(static, dev)
         torch.cuda.synchronize(dev)
         _lib.check(lib.gp_timing_begin(stream), "gp_timing_begin")
         for _ in range(reps):
-            net_e.forward_device(static, dev)
+            serial.forward_device(static, dev)
         _lib.check(lib.gp_timing_end(), "gp_timing_end")
+        serial.use_graph = graph_was
         classes = {}
         for c, name in enumerate(_lib.KC_NAMES):
             n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -176,40 +203,89 @@ def main():
             if n.value:
                 classes[name] = {"launches_per_step": n.value // reps, "ms_per_step": round(ms.value / reps, 4),
                                  "avg_launch_us": round(ms.value / n.value * 1e3, 2),
-                                 "tflops": round(fl.value / ms.value / 1e9, 2), "gbs": round(by.value / ms.value / 1e6, 1)}
+                                 "tflops": round(fl.value / ms.value / 1e9, 2), "gbs": round(by.value / ms.value / 1e6, 1),
+                                 "alg_bytes_per_launch": round(by.value / n.value), "alg_flop_per_launch": round(fl.value / n.value)}
+        top = []
+        for r in range(64):
+            lab = ctypes.create_string_buffer(160)
+            c, n, ms, fl, by = ctypes.c_int(), ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            if lib.gp_timing_top(r, lab, 160, ctypes.byref(c), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) != 0:
+                break
+            mfma = c.value == _lib.KC_GEMM
+            ach = fl.value / ms.value / 1e9 if mfma else by.value / ms.value / 1e6
+            top.append({"kernel": lab.value.decode(), "launches_per_step": n.value // reps, "ms_per_step": round(ms.value / reps, 4),
+                        "avg_launch_us": round(ms.value / n.value * 1e3, 2), "bound": "mfma" if mfma else "hbm",
+                        "achieved": round(ach, 1), "unit": "TFLOP/s" if mfma else "GB/s",
+                        "frac": round(ach / (peak if mfma else PEAK_HBM_GBS), 4)})
         g = classes["gemm"]
-        peak = PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3
-        line["roofline"] = {"kernel": "gemm_kernel<f16> (MFMA GEMM + implicit-GEMM conv, all launches of a step)",
+        line["roofline"] = {"kernel": "MFMA GEMM class (gp_gemm + gp_convnext_mlp: plain / implicit-GEMM conv / window conv / fused MLP), all launches of a step",
                             "bound": "mfma", "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
                             "frac": round(g["tflops"] / peak, 4), "traffic": None,
-                            "launches_per_step": g["launches_per_step"], "avg_launch_us": g["avg_launch_us"]}
+                            "launches_per_step": g["launches_per_step"], "avg_launch_us": g["avg_launch_us"],
+                            "alg_flop_per_launch": g["alg_flop_per_launch"], "alg_bytes_per_launch": g["alg_bytes_per_launch"],
+                            "kernels": top[:3]}
         if "dcnv3" in classes:
             d = classes["dcnv3"]
             line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
-                                       "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None}
-        # HBM traffic of the same kernels from PMC counters (collected with rocprofv3 in separate passes and
-        # committed under profiles/; bench.py itself cannot read PMCs): bytes per gp_gemm launch, FETCH_SIZE x2-corrected
-        pmc = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("pmc_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+                                       "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None,
+                                       "alg_bytes_per_launch": d["alg_bytes_per_launch"]}
+        # HBM traffic of the same kernel classes from PMC counters (rocprofv3 --pmc passes, FETCH_SIZE/WRITE_SIZE corrected as
+        # the microarch guide prescribes; scripts/pmc_traffic.py): bench.py itself cannot read PMCs, so it quotes the newest
+        # committed profile of this workload and says which commit it was taken on
+        pdir = os.path.join(ROOT, "profiles")
+        pmc = sorted(p for p in os.listdir(pdir) if p.endswith("pmc_traffic.json")) if os.path.isdir(pdir) else []
         if pmc and args.batch == 64 and args.dtype == "f16" and args.workload == "full":
-            t = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["classes"]
+            tj = json.load(open(os.path.join(pdir, pmc[-1])))
+            t = tj["classes"]
             line["roofline"]["traffic"] = round(t["gemm"]["hbm_bytes_per_step"] / g["launches_per_step"])
-            line["roofline"]["traffic_unit"] = "HBM bytes per launch (profiles/%s); algorithmic bytes per launch = %d" % (
-                pmc[-1], round(g["gbs"] * 1e9 * g["avg_launch_us"] * 1e-6))
+            line["roofline"]["traffic_source"] = {"file": "profiles/" + pmc[-1], "commit": tj.get("commit", "unknown (round 1)"),
+                                                  "unit": "HBM bytes per launch, class average"}
             if "dcnv3" in classes and "dcnv3" in t:
                 line["roofline_gather"]["traffic"] = round(t["dcnv3"]["hbm_bytes_per_step"] / classes["dcnv3"]["launches_per_step"])
         line["kernel_classes"] = classes
+        line["kernels_top8"] = top[:8]
         line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
 
+    if rank == 0:
+        note("roofline leg done")
+    # ---------------- parity mode: fp32 storage, the mode that meets 1e-4 (rank 0; serial; a few steps)
+    if rank == 0 and not args.no_parity and args.dtype == "f16":
+        netp = PoseNet(cfg, dtype=torch.float32, seed=0, use_graph=not args.no_graph, inflight=1).to(dev)
+        stp = netp.static_inputs(B, dev)
+        for k, v in host.items():
+            stp[k].copy_(torch.from_numpy(v).reshape(stp[k].shape))
+        for _ in range(3):
+            op = netp.forward_device(stp, dev)
+        torch.cuda.synchronize(dev)
+        n_p = 5
+        t0 = time.perf_counter()
+        for _ in range(n_p):
+            op = netp.forward_device(stp, dev)
+        torch.cuda.synchronize(dev)
+        pdt = time.perf_counter() - t0
+        st0 = serial.static_inputs(B, dev)
+        for k, v in host.items():
+            st0[k].copy_(torch.from_numpy(v).reshape(st0[k].shape))
+        of = serial.forward_device(st0, dev)
+        torch.cuda.synchronize(dev)
+        line["parity_mode"] = {"dtype": "f32", "value": round(B * n_p / pdt, 2), "unit": "images/s (one rank, one batch in flight)",
+                               "ms_per_step": round(pdt / n_p * 1e3, 3), "vs_reference": VS_REFERENCE["f32"],
+                               "path_roofline_frac_mfma_f32": round(B * n_p / pdt * GFLOP_PER_CROP[args.workload] * 1e9 / (PEAK_F32_TFLOPS * 1e12), 4),
+                               "fast_vs_parity_max_abs": {k: float((of[k].float() - op[k].float()).abs().max()) for k in ("rot", "trans", "size")}}
+        del netp
+
+    if rank == 0:
+        note("parity leg done")
     # ---------------- H->D inclusive rate (never `value`): the boundary hands over host tensors, so time
     # the same step with every input copied from pinned host memory first, copy and step serialised (no overlap)
-    if rank == 0 and not args.no_roofline:
-        net.use_graph = not args.no_graph
+    if rank == 0 and not args.no_roofline and not args.no_h2d:
+        static = serial.static_inputs(B, dev)
         pinned = {k: torch.from_numpy(v).reshape(static[k].shape).to(static[k].dtype).pin_memory() for k, v in host.items()}
         def step_h2d():
             for k, v in pinned.items():
                 static[k].copy_(v, non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()
-            net.forward_device(static, dev)
+            serial.forward_device(static, dev)
         for _ in range(3):
             step_h2d()
         torch.cuda.synchronize(dev)
@@ -240,7 +316,7 @@ def main():
             masks_d.copy_(masks_h, non_blocking=True)
             cropper(frames_d, masks_d, fidx, midx, boxes, out=static)
             torch.cuda.current_stream(dev).synchronize()
-            net.forward_device(static, dev)
+            serial.forward_device(static, dev)
         for _ in range(3):
             step_crop()
         torch.cuda.synchronize(dev)
@@ -254,26 +330,44 @@ def main():
                                              "host_bytes_per_step": int(frames_h.numel() + masks_h.numel() + B * 120),
                                              "note": "uint8 frames + masks + boxes -> HBM, gp_crop_rois, then the step; serialised"}
 
-    # ---------------- CPU baseline: oracle on the host cores, bounded sample
+    if rank == 0:
+        note("h2d legs done")
+    # ---------------- CPU baseline: the oracle on all host cores, bounded sample (B=64 and B=1, median)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import posenet_ref as O
         P = O.load_params(synth.synth_state_dict(cfg, 0))
-        nb = 2
-        sample = {k: torch.from_numpy(v) for k, v in synth.synth_batch(nb, seed=1000).items()}
-        torch.set_num_threads(min(os.cpu_count() or 1, 32))   # oversubscribing >32 threads slows the small ops down
-        with torch.no_grad():
-            O.posenet_forward_ref(P, sample, cfg)
-            n_it, t0 = 0, time.perf_counter()
-            while True:
-                O.posenet_forward_ref(P, sample, cfg)
-                n_it += 1
-                if time.perf_counter() - t0 > 12.0 or n_it >= 20:
-                    break
-            cdt = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": round(nb * n_it / cdt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
-                                "kind": "port", "sample": f"{n_it} x batch of {nb} crops, fp32 PyTorch-CPU oracle (oracle/posenet_ref.py)"}
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        def cpu_time(nb, warm, iters, budget):
+            sample = {k: torch.from_numpy(v) for k, v in synth.synth_batch(nb, seed=1000).items()}
+            ts = []
+            with torch.no_grad():
+                for _ in range(warm):
+                    O.posenet_forward_ref(P, sample, cfg)
+                t_start = time.perf_counter()
+                for _ in range(iters):
+                    t0 = time.perf_counter()
+                    O.posenet_forward_ref(P, sample, cfg)
+                    ts.append(time.perf_counter() - t0)
+                    if time.perf_counter() - t_start > budget:
+                        break
+            return statistics.median(ts), len(ts)
+        note(f"cpu baseline on {cores} threads")
+        t1, n1 = cpu_time(1, 2, 10, 6.0)
+        note(f"cpu B=1: {t1:.3f} s")
+        tB, nB = cpu_time(B, 1, 3, 18.0)
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            model = "unknown"
+        line["cpu_baseline"] = {"value": round(B / tB, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": f"median of {nB} passes over one batch of {B} crops (after 1 warm-up), fp32 PyTorch-CPU oracle "
+                                          f"(oracle/posenet_ref.py), {cores} threads on {model}",
+                                "b1": {"value": round(1.0 / t1, 3), "unit": "images/s", "sample": f"median of {n1} single-crop passes"}}
 
     if rank == 0:
+        if commit:
+            line["commit"] = commit
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

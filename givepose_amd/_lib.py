@@ -70,6 +70,7 @@ PROTOTYPES = {
     "gp_timing_begin": ([_P], c_int),
     "gp_timing_end": ([], c_int),
     "gp_timing_report": ([c_int, POINTER(c_long), POINTER(c_double), POINTER(c_double), POINTER(c_double)], c_int),
+    "gp_timing_top": ([c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_long), POINTER(c_double), POINTER(c_double), POINTER(c_double)], c_int),
 }
 
 _lib = None

@@ -33,6 +33,7 @@ int gp_fail(int code, const char* fmt, ...);
 // per-launch timing hooks (bench.py's roofline leg); no-ops unless gp_timing_begin() was called
 void gp_timing_before(hipStream_t s, int cls, double flops, double bytes);
 int gp_timing_after(const char* name);
+void gp_timing_label(const char* fmt, ...);   // optional, between before/after: groups the launch under this label in gp_timing_top
 
 // ---------------------------------------------------------------------------------- vectors
 // One 16-byte vector of T: 8 halfs or 4 floats.

@@ -306,6 +306,7 @@ extern "C" int gp_dcnv3_forward(const void* in, const void* offset, const void* 
     // algorithmic bytes: input once + consumed offset/mask + output
     const double bytes = (double)N * H * W * G * D * esz + (double)p.rows * G * P * 3 * osz + (double)p.rows * G * D * esz;
     gp_timing_before(s, GP_KC_DCNV3, (double)p.rows * G * D * P * 8.0, bytes);
+    gp_timing_label("dcnv3 N%d %dx%d s%d G%d D%d", N, H, W, stride, G, D);
     if (dtype == GP_F16 && om_dtype == GP_F16) launch<half_t, half_t>(p, s);
     else if (dtype == GP_F16) launch<half_t, float>(p, s);
     else if (om_dtype == GP_F16) launch<float, half_t>(p, s);

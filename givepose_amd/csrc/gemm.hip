@@ -1067,6 +1067,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
     GP_REQUIRE(variant >= 2 && variant <= 13 && variant != 6 && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
+    if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "");
+    else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "");
     if (variant == 13) {
         GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
         p.tiles_m = d->M / 256;

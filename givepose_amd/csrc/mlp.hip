@@ -286,6 +286,7 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
     const double flops = 2.0 * 2.0 * (double)M * C * 4 * C;
     const double bytes = 3.0 * M * C * 2 + 2.0 * 4 * C * C * 2;
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
+    gp_timing_label("convnext_mlp C%d M%ld", C, M);
     if (C == 128) hipLaunchKernelGGL(convnext_mlp_kernel<128>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(convnext_mlp_kernel<256>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
     GP_LAUNCH_CHECK("gp_convnext_mlp");

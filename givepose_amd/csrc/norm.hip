@@ -923,6 +923,7 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     const long strips = (n_pixels + 7) / 8;
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
+    gp_timing_label("dwconv%d_ln C%d %dx%d B%d", KS, C, H, W, B);
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && H % 4 == 0 && W % 16 == 0 &&
@@ -1022,6 +1023,7 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C, (double)B * HW * C * esz * 2);
+    gp_timing_label("gn_apply C%d HW%d act%d", C, HW, act);
     const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW)), pxb = gn_apply_pxb(B, HW);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
@@ -1041,6 +1043,7 @@ extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const
     GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_apply_xyz: unsupported C=%d G=%d", C, G);
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 10.0 * B * HW * C, (double)B * HW * (C * esz + 28));
+    gp_timing_label("gn_apply_xyz C%d HW%d", C, HW);
     const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW)), pxb = gn_apply_pxb(B, HW);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);

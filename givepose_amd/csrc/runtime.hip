@@ -1,6 +1,9 @@
 // Error reporting, device info, hipGraph capture and per-launch event timing.
 #include <stdarg.h>
 
+#include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -65,6 +68,7 @@ struct Rec {
     int cls;
     double flops, bytes;
     const char* name;
+    std::string label;
 };
 bool g_timing = false;
 hipStream_t g_tstream = nullptr;
@@ -75,7 +79,9 @@ bool g_open = false;
 struct Acc {
     long n = 0;
     double ms = 0, flops = 0, bytes = 0;
+    int cls = 0;
 } g_acc[GP_KC_COUNT];
+std::vector<std::pair<std::string, Acc>> g_top;
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) {
@@ -96,8 +102,19 @@ void gp_timing_before(hipStream_t s, int cls, double flops, double bytes) {
     g_cur.cls = cls;
     g_cur.flops = flops;
     g_cur.bytes = bytes;
+    g_cur.label.clear();
     hipEventRecord(g_cur.a, s);
     g_open = true;
+}
+
+void gp_timing_label(const char* fmt, ...) {
+    if (!g_open) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_cur.label = buf;
 }
 
 int gp_timing_after(const char* name) {
@@ -114,6 +131,7 @@ extern "C" int gp_timing_begin(void* stream) {
     g_tstream = (hipStream_t)stream;
     g_recs.clear();
     for (auto& a : g_acc) a = Acc();
+    g_top.clear();
     g_timing = true;
     return GP_OK;
 }
@@ -126,20 +144,29 @@ extern "C" int gp_timing_end(void) {
     const char* dump = getenv("GP_TIMING_DUMP");
     FILE* df = dump ? fopen(dump, "w") : nullptr;
     int seq = 0;
+    std::map<std::string, Acc> by_label;
     for (auto& r : g_recs) {
         float ms = 0;
         hipEventElapsedTime(&ms, r.a, r.b);
-        if (df) fprintf(df, "%d %d %s %.2f %.0f %.0f\n", seq++, r.cls, r.name ? r.name : "?", ms * 1e3, r.flops, r.bytes);
+        if (df) fprintf(df, "%d %d %s %.2f %.0f %.0f %s\n", seq++, r.cls, r.name ? r.name : "?", ms * 1e3, r.flops, r.bytes, r.label.c_str());
         Acc& a = g_acc[r.cls];
         a.n++;
         a.ms += ms;
         a.flops += r.flops;
         a.bytes += r.bytes;
+        Acc& t = by_label[r.label.empty() ? std::string(r.name ? r.name : "?") : r.label];
+        t.n++;
+        t.ms += ms;
+        t.flops += r.flops;
+        t.bytes += r.bytes;
+        t.cls = r.cls;
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
     if (df) fclose(df);
     g_recs.clear();
+    g_top.assign(by_label.begin(), by_label.end());
+    std::sort(g_top.begin(), g_top.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
     return GP_OK;
 }
 
@@ -149,5 +176,17 @@ extern "C" int gp_timing_report(int cls, long* launches, double* ms, double* flo
     *ms = g_acc[cls].ms;
     *flops = g_acc[cls].flops;
     *bytes = g_acc[cls].bytes;
+    return GP_OK;
+}
+
+extern "C" int gp_timing_top(int rank, char* label, int label_len, int* cls, long* launches, double* ms, double* flops, double* bytes) {
+    if (rank < 0 || rank >= (int)g_top.size()) return gp_fail(GP_ERR_INVALID, "gp_timing_top: rank %d of %d", rank, (int)g_top.size());
+    const auto& e = g_top[rank];
+    if (label && label_len > 0) {
+        strncpy(label, e.first.c_str(), label_len - 1);
+        label[label_len - 1] = 0;
+    }
+    if (cls) *cls = e.second.cls;
+    *launches = e.second.n; *ms = e.second.ms; *flops = e.second.flops; *bytes = e.second.bytes;
     return GP_OK;
 }

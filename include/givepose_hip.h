@@ -267,6 +267,9 @@ enum gp_kernel_class {
 int gp_timing_begin(void* stream);
 int gp_timing_end(void);
 int gp_timing_report(int cls, long* launches, double* ms, double* flops, double* bytes);
+/* The same launches grouped by kernel label (entry point + shape, e.g. "gemm v10 M16384 N2048 K512 epi1"), sorted by
+ * total time: rank 0 is the most expensive.  Returns GP_ERR_INVALID past the last group. */
+int gp_timing_top(int rank, char* label, int label_len, int* cls, long* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }
