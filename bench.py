@@ -43,9 +43,10 @@ GFLOP_PER_CROP = {"full": 67.517, "nodcn": 66.506, "resnet34": 36.81, "resnet34_
 PEAK_F16_TFLOPS = 2500.0                                 # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3                                  # fp32 MFMA
 PEAK_HBM_GBS = 8000.0
-# measured against the reference golden vectors / the oracle in tests/test_hip_posenet.py (max abs error, B in {1,4,5,64})
-VS_REFERENCE = {"f32": {"rot": 4e-5, "trans": 5e-6, "size": 1.3e-5, "meets_1e-4": True},
-                "f16": {"rot": 1.5e-2, "trans": 1.6e-3, "size": 1.1e-2, "meets_1e-4": False,
+# measured against the reference golden vectors (B in {1,4,5}) and the oracle at the bench shape (worst crop of 64):
+# tests/test_hip_posenet.py::test_fp32_bs64_matches_oracle / test_fp16_bs64_close_to_oracle, max abs error
+VS_REFERENCE = {"f32": {"rot": 7.3e-5, "trans": 5.6e-6, "size": 1.6e-5, "meets_1e-4": True},
+                "f16": {"rot": 3.6e-2, "trans": 4.3e-3, "size": 1.5e-2, "meets_1e-4": False,
                         "note": "fp16 operands cannot meet 1e-4: rounding the weights alone gives 1.5e-3 (tests/precision_model.py)"}}
 
 

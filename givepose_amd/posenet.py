@@ -363,7 +363,17 @@ class PoseNet(nn.Module):
         feat2d = feat.view(B * 64, fc)
         ops.size_head(feat.view(B, 64, fc), W["size.w1"], W["size.b1"], W["size.w2"], W["size.b2"], buf["mean_size"], buf["size"], buf["size_scratch"])
         self._xyz_head(W, "xyz_nocs_head", feat2d, B, buf, buf["nocs_nchw"], buf["nocs_nhwc4"])
-        # ---- MAPEncoder (network/conv_pnp_net.py:303-332)
+        self._seq_encoder(B, plan)
+        cat2d = buf["feat_cat"].view(B * 64, 512)
+        ops.gemm(feat2d, W["red.w"], cat2d, bias=W["red.b"], ldc=512)
+        self._xyz_head(W, "xyz_deform_head", cat2d, B, buf, buf["ivfc_nchw"], buf["ivfc_nhwc4"])
+        self._seq_pnp(B, plan)
+
+    def _seq_encoder(self, B, plan, only_layer=None, weights_of=None):
+        """nocs_nhwc4 -> right half of feat_cat.  MAPEncoder (network/conv_pnp_net.py:303-332) or MAPTransformerEncoer.
+        only_layer (tests): run DCNv3_C layer `only_layer` alone on buf["e_o{only_layer-1}"] (with the weights of layer
+        `weights_of`, default its own) and stop before its GroupNorm."""
+        W, buf, cfg = self._packed, plan["buf"], self.cfg
         cat2d = buf["feat_cat"].view(B * 64, 512)
         prev = None
         if cfg.nocsmap_encoder == "att":
@@ -385,6 +395,12 @@ class PoseNet(nn.Module):
         for li, r in enumerate((64, 32, 16) if cfg.nocsmap_encoder == "conv" else ()):
             q = f"enc{li}."
             ro = r // 2
+            if only_layer is not None:
+                if li != only_layer:
+                    continue
+                prev = buf[f"e_o{li - 1}"]
+                if weights_of is not None:
+                    q = f"enc{weights_of}."
             if cfg.use_dcn == "dcnv3":
                 xin = buf[f"e_in{li}"]
                 nq = B * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
@@ -404,6 +420,8 @@ class PoseNet(nn.Module):
                 ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"],
                          gn=self._gnarg(buf, ro * ro))
                 fused = True
+                if only_layer is not None:
+                    return
             else:
                 y = buf[f"e_o{li}"]
                 fused = li > 0
@@ -416,9 +434,10 @@ class PoseNet(nn.Module):
                 prev = y
             else:   # last layer normalises straight into the right half of feat_cat (PoseNet.py:193)
                 self._gn(y, W[q + "gn_w"], W[q + "gn_b"], ACT_RELU, buf, out=cat2d[:, 256:], ldy=512, fused=fused)
-        ops.gemm(feat2d, W["red.w"], cat2d, bias=W["red.b"], ldc=512)
-        self._xyz_head(W, "xyz_deform_head", cat2d, B, buf, buf["ivfc_nchw"], buf["ivfc_nhwc4"])
-        # ---- ConvPnPNet (network/conv_pnp_net.py:137-201)
+
+    def _seq_pnp(self, B, plan):
+        """ivfc_nhwc4 + roi_coord_2d -> rot6d / pred_t / rot / trans: ConvPnPNet (network/conv_pnp_net.py:137-201) + pose decode."""
+        W, buf, cfg = self._packed, plan["buf"], self.cfg
         R = cfg.out_res
         p = ops.pnp_conv1(buf["ivfc_nhwc4"], buf["roi_coord_2d"], W["pnp.c0_w"], buf["p0"], B, R)
         self._gn(p, W["pnp.g0_w"], W["pnp.g0_b"], ACT_RELU, buf)
@@ -496,6 +515,66 @@ class PoseNet(nn.Module):
                 "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
                 "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf.get(f"x{len(self.cfg.convnext_dims) - 1}"),
                 "feat_cat": buf["feat_cat"]}
+
+    # ---- sub-sequences of the path, eager, for the per-module golden vectors (tests/test_hip_modules.py); every one
+    #      runs exactly the launches forward_device runs for that module, on the same plan buffers
+    def _module_plan(self, B, device):
+        device = torch.device(device)
+        _lib.load()
+        if self._packed is None:
+            self._pack(device)
+        return self._plan(B, device, 0)
+
+    @torch.no_grad()
+    def run_xyz_head(self, head, feat_nchw, device="cuda"):
+        """TopDownXyzHead.forward (network/xyz_head.py:349-366): (B,Cin,8,8) -> (B,3,64,64) fp32; head in
+        {"xyz_nocs_head", "xyz_deform_head"}."""
+        B, C = feat_nchw.shape[:2]
+        plan = self._module_plan(B, device)
+        buf = plan["buf"]
+        x = feat_nchw.to(device).permute(0, 2, 3, 1).reshape(B * 64, C).to(self.compute_dtype).contiguous()
+        key = "nocs" if head == "xyz_nocs_head" else "ivfc"
+        self._xyz_head(self._packed, head, x, B, buf, buf[key + "_nchw"], buf[key + "_nhwc4"])
+        return buf[key + "_nchw"].clone()
+
+    @torch.no_grad()
+    def run_map_encoder(self, coor_nchw, device="cuda"):
+        """MAPEncoder.forward (network/conv_pnp_net.py:303-332) / MAPTransformerEncoer: (B,3,64,64) -> (B,256,8,8) fp32."""
+        B = coor_nchw.shape[0]
+        plan = self._module_plan(B, device)
+        buf = plan["buf"]
+        buf["nocs_nhwc4"].zero_()
+        buf["nocs_nhwc4"][:, :3] = coor_nchw.to(device).float().permute(0, 2, 3, 1).reshape(-1, 3)
+        self._seq_encoder(B, plan)
+        return buf["feat_cat"].view(B, 8, 8, 512)[..., 256:].permute(0, 3, 1, 2).float().contiguous()
+
+    @torch.no_grad()
+    def run_dcnv3_c(self, layer, x_nchw, device="cuda", weights_of=None):
+        """DCNv3_C.forward (network/dcnv3.py:32-38 -> ops_dcnv3/modules/dcnv3.py:318-356) at the geometry of MAPEncoder
+        layer `layer` in {1, 2} (r = 32 / 16) with the weights of layer `weights_of` (default `layer`):
+        (B,256,r,r) -> (B,256,r/2,r/2) fp32, before the layer's GroupNorm."""
+        assert self.cfg.use_dcn == "dcnv3" and layer in (1, 2) and weights_of in (None, 1, 2)
+        B = x_nchw.shape[0]
+        plan = self._module_plan(B, device)
+        buf = plan["buf"]
+        buf[f"e_o{layer - 1}"].copy_(x_nchw.to(device).permute(0, 2, 3, 1).to(self.compute_dtype))
+        self._seq_encoder(B, plan, only_layer=layer, weights_of=weights_of)
+        return buf[f"e_o{layer}"].permute(0, 3, 1, 2).float().contiguous()
+
+    @torch.no_grad()
+    def run_pnp(self, x_nchw, data, device="cuda"):
+        """ConvPnPNet.forward (network/conv_pnp_net.py:137-201) on x = cat(coor, roi_coord_2d) (B,5,64,64): returns
+        (rot6d (B,6), t (B,3)); `data` supplies the camera scalars the fused pose tail also reads."""
+        B = x_nchw.shape[0]
+        plan = self._module_plan(B, device)
+        buf = plan["buf"]
+        for k in ("cam_K", "roi_wh", "bbox_center", "resize_ratio"):
+            buf[k].copy_(data[k].reshape(buf[k].shape))
+        buf["ivfc_nhwc4"].zero_()
+        buf["ivfc_nhwc4"][:, :3] = x_nchw[:, :3].to(device).float().permute(0, 2, 3, 1).reshape(-1, 3)
+        buf["roi_coord_2d"].copy_(x_nchw[:, 3:5])
+        self._seq_pnp(B, plan)
+        return buf["rot6d"].clone(), buf["pred_t"].clone()
 
     def static_inputs(self, B, device="cuda", slot=0):
         """The plan's device-resident input buffers (fill these to skip the per-call H->D copies)."""

@@ -5,8 +5,8 @@
 
 Tolerances (north_star: 1e-4 abs on R/t/s):
   fp32 storage + fp32 MFMA accumulate : R, t, s <= 1e-4 abs; coordinate maps <= 2e-4 abs; mask bit-exact.
-  fp16 storage (throughput mode)      : R <= 3e-2, t/s <= 3e-2 relative-to-scale, maps <= 2e-2 abs -- fp16
-      rounding through 36 ConvNeXt blocks; reported, not claimed to meet 1e-4.
+  fp16 storage (throughput mode)      : R <= 3e-2 (B <= 5) / 6e-2 (worst crop of 64), t/s <= 3e-2 relative-to-scale,
+      maps <= 2e-2 abs -- fp16 operand rounding (weights alone: 1.5e-3 on R); reported, not claimed to meet 1e-4.
 """
 import numpy as np
 import pytest
@@ -23,6 +23,26 @@ def _model(dtype, **kw):
 def _batch(B, seed):
     from givepose_amd import synth
     return {k: torch.from_numpy(v) for k, v in synth.synth_batch(B, seed=seed).items()}
+
+
+def _launch_labels(net, data):
+    """{kernel label: launches} of one eager forward (gp_timing_top), to assert WHICH kernels a configuration runs."""
+    import ctypes
+    from givepose_amd import _lib
+    lib = _lib.load()
+    net.forward_device(data)
+    torch.cuda.synchronize()
+    _lib.check(lib.gp_timing_begin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "gp_timing_begin")
+    net.forward_device(data)
+    _lib.check(lib.gp_timing_end(), "gp_timing_end")
+    out = {}
+    for r in range(500):
+        lab = ctypes.create_string_buffer(160)
+        c, n, ms, fl, by = ctypes.c_int(), ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        if lib.gp_timing_top(r, lab, 160, ctypes.byref(c), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)) != 0:
+            break
+        out[lab.value.decode()] = n.value
+    return out
 
 
 @pytest.fixture(scope="module")
@@ -50,6 +70,7 @@ def test_fp32_matches_reference_golden(golden, net32, B):
     err = {k: float(np.abs(out[k].cpu().numpy() - z["out_" + k]).max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print(B, err)
     assert np.abs(feat - z["mid_feat"]).max() < 2e-4
+    assert np.abs(mid["rot6d"] - z["mid_rot6d"]).max() < 1e-4 and np.abs(mid["pred_t"] - z["mid_pred_t"]).max() < 1e-4
     assert err["nocs_coor"] < 2e-4 and err["ivfc_coor"] < 2e-4
     assert err["rot"] < 1e-4 and err["trans"] < 1e-4 and err["size"] < 1e-4
 
@@ -68,7 +89,56 @@ def test_fp32_matches_oracle_other_batch(net32):
     assert torch.equal(out["mask"].cpu(), ref["mask"])
 
 
-@pytest.mark.parametrize("B", [4, 5])
+@pytest.fixture(scope="module")
+def oracle64():
+    """The oracle on the bench shape (64 crops; crop b reads the offset rows of crop b // 4, npre = nq + r + 8 rows of the
+    prefix are computed), once per wiring: {use_dcn: (data, reference outputs)}."""
+    from givepose_amd import synth
+    from givepose_amd.config import PoseNetConfig
+    from oracle import posenet_ref as O
+    cache = {}
+
+    def get(use_dcn):
+        if use_dcn not in cache:
+            cfg = PoseNetConfig(use_dcn=use_dcn)
+            data = _batch(64, 640)
+            torch.set_num_threads(min(16, torch.get_num_threads()))
+            cache[use_dcn] = (data, O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg))
+        return cache[use_dcn]
+    return get
+
+
+@pytest.mark.parametrize("use_dcn", ["dcnv3", ""])
+def test_fp32_bs64_matches_oracle(oracle64, use_dcn):
+    """BASELINE configs 2 and 1 at the bench batch: fp32 storage meets north_star's 1e-4 on R / t / s."""
+    data, ref = oracle64(use_dcn)
+    out = _model(torch.float32, use_dcn=use_dcn)(data, "cuda")
+    err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    print("fp32 bs64", repr(use_dcn), err)
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
+    assert err["rot"] < 1e-4 and err["trans"] < 1e-4 and err["size"] < 1e-4
+    assert err["nocs_coor"] < 2e-4 and err["ivfc_coor"] < 2e-4
+
+
+@pytest.mark.parametrize("use_dcn", ["dcnv3", ""])
+def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
+    """The benchmarked mode at the benchmarked shape (hipGraph replay, as bench.py runs it) against the oracle."""
+    from givepose_amd import PoseNet, PoseNetConfig
+    data, ref = oracle64(use_dcn)
+    net = PoseNet(PoseNetConfig(use_dcn=use_dcn), dtype=torch.float16, seed=0, use_graph=True).cuda()
+    for _ in range(3):
+        out = net(data, "cuda")
+    err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    print("fp16 bs64", repr(use_dcn), err)
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
+    assert err["nocs_coor"] < 2e-2 and err["ivfc_coor"] < 2e-2
+    # worst crop of 64 (measured 3.6e-2 on R: the rot6d -> R normalisation amplifies the fp16 error of the least
+    # well-conditioned crop); fp16 operands cannot meet 1e-4 at all -- tests/precision_model.py, DESIGN.md 5c
+    assert err["rot"] < 6e-2 and err["size"] < 3e-2
+    assert err["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max()))
+
+
+@pytest.mark.parametrize("B", [1, 4, 5])
 def test_fp16_close_to_reference_golden(golden, net16, B):
     z = golden(f"posenet_e2e_B{B}")
     out = net16(_batch(B, int(z["batch_seed"])), "cuda")
@@ -85,7 +155,16 @@ def test_fp16_alternative_block_paths_close_to_reference_golden(golden, kw):
     """The switchable ConvNeXt block paths (LayerNorm folded into fc1's epilogue at C = 512; unfused fc1 / fc2 at
     C = 128 / 256) meet the same fp16 tolerances as the default wiring."""
     z = golden("posenet_e2e_B4")
-    out = _model(torch.float16, **kw)(_batch(4, int(z["batch_seed"])), "cuda")
+    net = _model(torch.float16, **kw)
+    labels = _launch_labels(net, _batch(4, int(z["batch_seed"])))
+    if "defer_ln" in kw:      # 27 stage-2 blocks through the raw depth-wise kernel + LayerNorm folded into fc1's epilogue
+        assert sum(n for l, n in labels.items() if "gp_dwconv7_raw_stats" in l) == 27, labels
+        assert sum(n for l, n in labels.items() if "N2048 K512 epi6" in l) == 27, labels
+    else:                     # no fused MLP launch; stages 0-1 run fc1 / fc2 as GEMMs
+        assert not any("convnext_mlp" in l for l in labels), labels
+        assert sum(n for l, n in labels.items() if " N512 K128 epi1" in l or " N1024 K256 epi1" in l) == 6, labels
+    assert any("convnext_mlp" in l for l in _launch_labels(_model(torch.float16), _batch(4, 3)))   # the default wiring does fuse
+    out = net(_batch(4, int(z["batch_seed"])), "cuda")
     err = {k: float(np.abs(out[k].cpu().numpy() - z["out_" + k]).max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print("fp16", kw, err)
     assert err["nocs_coor"] < 2e-2 and err["ivfc_coor"] < 2e-2
