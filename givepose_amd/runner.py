@@ -59,3 +59,41 @@ class ShardRunner:
             return self.gathered[i]
         o = self.net._plan(self.B, self.dev, i)["buf"]
         return gd.pack_poses(o["rot_ego"].view(self.B, 3, 3), o["trans"], o["size"])
+
+
+def rank_selfcheck(rank, world, port, queue, batch=8, steps=6, inflight=2, backend="gloo", device_index=0):
+    """Entry point of ONE rank process of the N > 1 self-check (tests/test_multirank_gpu.py starts `world` of them from a
+    fork server that never touched the GPU): runs `steps` steps of the real step path (ShardRunner: slots in flight, one
+    comm stream, all-gather of the poses) and reports, per slot, the gathered (world*B, 15) poses of its last use next
+    to this rank's own poses computed strictly serially (eager, slot 0) on a separate PoseNet.  backend "gloo" lets every rank share
+    one GPU (RCCL refuses two ranks per device); the driver's real runs use "nccl" = RCCL with one rank per GPU."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        import torch.distributed as dist
+        from . import PoseNet, PoseNetConfig, synth
+        gd.init_from_env(backend=backend)
+        torch.cuda.set_device(device_index)
+        dev = torch.device("cuda", device_index)
+        cfg = PoseNetConfig()
+        net = PoseNet(cfg, dtype=torch.float16, seed=0, use_graph=True, inflight=inflight).to(dev)
+        run = ShardRunner(net, batch, dev, world)
+        batches = [synth.synth_batch(batch, seed=500 + 10 * rank + i) for i in range(run.NF)]
+        for i, b in enumerate(batches):
+            run.load(i, b)
+        for _ in range(steps):
+            run.step()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        gathered = [run.result(i).cpu().numpy() for i in range(run.NF)]
+        serial = PoseNet(cfg, dtype=torch.float16, seed=0, use_graph=False, inflight=inflight).to(dev)   # same tile choices, run strictly serially
+        own = []
+        for b in batches:
+            o = serial.forward_device({k: torch.from_numpy(v) for k, v in b.items()}, dev)
+            own.append(gd.pack_poses(o["rot"], o["trans"], o["size"]).cpu().numpy())
+        queue.put((rank, "ok", gathered, own))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:   # the parent must never wait for a dead rank
+        import traceback
+        queue.put((rank, "error: " + repr(e) + "\n" + traceback.format_exc(), None, None))

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-rank GPU tests need FRESH rank processes.  Start the multiprocessing fork server now -- before anything in this
+    # process initialises the GPU (torch.cuda.is_available() below already does) -- so that ranks are forked from a
+    # process that never touched it, instead of fork+exec'ing out of a GPU-initialised pytest process.
+    import multiprocessing.forkserver as fs
+    fs.ensure_running()
 
 
 def pytest_collection_modifyitems(config, items):
