@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
-GP_F32, GP_F16 = 0, 1
+GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
 KC_GEMM, KC_DCNV3, KC_DWCONV_LN, KC_NORM, KC_ELEMENTWISE, KC_SMALL, KC_COUNT = 0, 1, 2, 3, 4, 5, 6
@@ -37,6 +37,8 @@ PROTOTYPES = {
     "gp_version": ([], c_int),
     "gp_device_info": ([POINTER(c_int), c_char_p, c_int], c_int),
     "gp_dcnv3_forward": ([_P, _P, _P, _P] + [c_int] * 9 + [c_float] + [c_int] * 7 + [_P], c_int),
+    "gp_dcnv3_forward_any": ([_P] * 4 + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
+    "gp_dcnv3_backward": ([_P] * 7 + [c_long, c_long] + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_gemm": ([POINTER(GemmDesc), _P], c_int),
     "gp_convnext_mlp_pack_w2": ([_P, _P, c_int, _P], c_int),
     "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),

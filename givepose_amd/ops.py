@@ -11,9 +11,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, EPI_GELU, EPI_LNFOLD_GELU, EPI_LRELU, EPI_NONE, EPI_RELU, EPI_RES_RELU,
-                   EPI_SCALE_RES, GP_F16, GP_F32, GemmDesc, check)
+                   EPI_SCALE_RES, GP_F16, GP_F32, GP_F64, GemmDesc, check)
 
-__all__ = ["dtype_code", "gemm", "conv2d_nhwc", "dcnv3_forward", "dcnv3_forward_into", "convnext_stem", "dwconv_ln",
+__all__ = ["dtype_code", "gemm", "conv2d_nhwc", "dcnv3_forward", "dcnv3_backward", "dcnv3_forward_into", "convnext_stem", "dwconv_ln",
            "layernorm", "groupnorm", "upsample_bilinear2x", "deconv_col2im", "xyz_out_layer", "pointwise_k3",
            "pnp_conv1", "xyz_conv3x3_s2", "size_head", "pose_tail", "mask_resize_nearest"]
 
@@ -167,23 +167,71 @@ def dcnv3_forward_into(inp, offset, mask, out, K, stride, pad, dil, G, D, offset
     return out
 
 
+def _any_dtype(t):
+    if t.dtype == torch.float64:
+        return GP_F64
+    return dtype_code(t.dtype)
+
+
+def _dcn_out_hw(H, W_, kh, kw, sh, sw, ph, pw, dh, dw):
+    return (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W_ + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+
+
 def dcnv3_forward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                   group, group_channels, offset_scale, im2col_step, remove_center=0):
     """Drop-in for the reference pybind op ``DCNv3.dcnv3_forward`` (network/ops_dcnv3/src/vision.cpp:15,
-    dcnv3.h:20-38; called from functions/dcnv3_func.py:53): same argument list, channels-last tensors, returns a
-    freshly allocated (N,Ho,Wo,G*D) tensor.  offset/mask are consumed as flat buffers exactly like the CUDA kernel."""
-    if not (kernel_h == kernel_w and stride_h == stride_w and pad_h == pad_w and dilation_h == dilation_w):
-        raise NotImplementedError("gp_dcnv3_forward supports square kernels / strides / pads / dilations")
-    _contig(offset, "offset"), _contig(mask, "mask")
-    N, H, W_, _ = input.shape
-    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
-    Wo = (W_ + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    dcnv3.h:20-38; called from functions/dcnv3_func.py:53): same argument list, channels-last tensors of
+    float64 / float32 / float16, returns a freshly allocated (N,Ho,Wo,G*D) tensor.  offset/mask are consumed as flat
+    buffers exactly like the CUDA kernel.  The PoseNet geometry (square kernel, group_channels % 4 == 0, fp16 / fp32) runs
+    on the wave kernels of csrc/dcnv3.hip, everything else on the generic kernel of csrc/dcnv3_any.hip."""
+    _contig(_chk(input, "input"), "input"), _contig(_chk(offset, "offset"), "offset"), _contig(_chk(mask, "mask"), "mask")
+    N, H, W_, C = input.shape
+    if C != group * group_channels:
+        raise RuntimeError(f"Input channels and group times group channels wont match: ({C} vs {group * group_channels}).")
+    Ho, Wo = _dcn_out_hw(H, W_, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w)
     need = N * Ho * Wo * group * (kernel_h * kernel_w - int(remove_center))
     if offset.numel() < need * 2 or mask.numel() < need:
         raise RuntimeError("offset/mask buffers smaller than the kernel consumes")
-    out = torch.empty(N, Ho, Wo, group * group_channels, dtype=input.dtype, device=input.device)
-    return dcnv3_forward_into(input, offset, mask, out, kernel_h, stride_h, pad_h, dilation_h, group, group_channels,
-                              offset_scale, im2col_step, remove_center)
+    out = torch.empty(N, Ho, Wo, C, dtype=input.dtype, device=input.device)
+    square = kernel_h == kernel_w and stride_h == stride_w and pad_h == pad_w and dilation_h == dilation_w
+    if square and group_channels % 4 == 0 and input.dtype in (torch.float16, torch.float32):
+        return dcnv3_forward_into(input, offset, mask, out, kernel_h, stride_h, pad_h, dilation_h, group, group_channels,
+                                  offset_scale, im2col_step, remove_center)
+    if not (offset.dtype == mask.dtype == input.dtype):
+        raise TypeError("input, offset and mask must share a dtype")
+    check(_L().gp_dcnv3_forward_any(_ptr(input), _ptr(offset), _ptr(mask), _ptr(out), N, H, W_, group, group_channels,
+                                    kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                    float(offset_scale), int(remove_center), int(im2col_step), _any_dtype(input), _stream()),
+          "gp_dcnv3_forward_any")
+    return out
+
+
+def dcnv3_backward(input, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                   group, group_channels, offset_scale, grad_output, im2col_step, remove_center=0):
+    """Drop-in for ``DCNv3.dcnv3_backward`` (network/ops_dcnv3/src/dcnv3.h:40-59; called from functions/dcnv3_func.py:79-84):
+    returns [grad_input, grad_offset, grad_mask] shaped like input / offset / mask, in the input dtype (computed in
+    opmath precision and, for float16, rounded at the end: dcnv3_cuda.cu:123-126, 167-173)."""
+    for t, n in ((input, "input"), (offset, "offset"), (mask, "mask"), (grad_output, "grad_output")):
+        _contig(_chk(t, n), n)
+    if not (offset.dtype == mask.dtype == grad_output.dtype == input.dtype):
+        raise TypeError("input, offset, mask and grad_output must share a dtype")
+    N, H, W_, C = input.shape
+    if C != group * group_channels:
+        raise RuntimeError(f"Input channels and group times group channels wont match: ({C} vs {group * group_channels}).")
+    Ho, Wo = _dcn_out_hw(H, W_, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w)
+    if tuple(grad_output.shape) != (N, Ho, Wo, C):
+        raise RuntimeError(f"grad_output shape {tuple(grad_output.shape)} != {(N, Ho, Wo, C)}")
+    acc = torch.float64 if input.dtype == torch.float64 else torch.float32
+    gi = torch.empty(input.shape, dtype=acc, device=input.device)
+    go = torch.empty(offset.shape, dtype=acc, device=input.device)
+    gm = torch.empty(mask.shape, dtype=acc, device=input.device)
+    check(_L().gp_dcnv3_backward(_ptr(input), _ptr(offset), _ptr(mask), _ptr(grad_output), _ptr(gi), _ptr(go), _ptr(gm),
+                                 offset.numel(), mask.numel(), N, H, W_, group, group_channels, kernel_h, kernel_w, stride_h,
+                                 stride_w, pad_h, pad_w, dilation_h, dilation_w, float(offset_scale), int(remove_center),
+                                 int(im2col_step), _any_dtype(input), _stream()), "gp_dcnv3_backward")
+    if input.dtype == torch.float16:
+        return [gi.half(), go.half(), gm.half()]
+    return [gi, go, gm]
 
 
 # ----------------------------------------------------------------------------------- norms & small ops

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 enum gp_status { GP_OK = 0, GP_ERR_INVALID = -1, GP_ERR_LAUNCH = -2, GP_ERR_RUNTIME = -3 };
-enum gp_dtype { GP_F32 = 0, GP_F16 = 1 };
+enum gp_dtype { GP_F32 = 0, GP_F16 = 1, GP_F64 = 2 /* gp_dcnv3_forward_any / gp_dcnv3_backward only */ };
 enum gp_act { GP_ACT_NONE = 0, GP_ACT_GELU = 1, GP_ACT_RELU = 2, GP_ACT_LRELU = 3 /* slope 0.1 */ };
 /* GEMM epilogues: v = acc + bias; then */
 enum gp_epilogue {
@@ -63,6 +63,27 @@ int gp_dcnv3_forward(const void* in, const void* offset, const void* mask, void*
                      int G, int D, int K, int stride, int pad, int dil, float offset_scale,
                      int remove_center, int im2col_step, int off_ld, int mask_ld, int mask_is_logits,
                      int dtype, int om_dtype, void* stream);
+
+/* The same operator at the reference's full breadth: the argument list of DCNv3.dcnv3_forward itself
+ * (dcnv3.h:20-38: kernel / stride / pad / dilation per axis, any group_channels) and its dtype dispatch
+ * (dcnv3_cuda.cu:68: GP_F64 / GP_F32 / GP_F16; opmath = double for double, float otherwise).  offset / mask are
+ * contiguous flat buffers of `dtype` with the reference addressing (off_ld = G*P*2, mask_ld = G*P). */
+int gp_dcnv3_forward_any(const void* in, const void* offset, const void* mask, void* out, int N, int H, int W, int G,
+                         int D, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                         int dilation_h, int dilation_w, float offset_scale, int remove_center, int im2col_step,
+                         int dtype, void* stream);
+
+/* DCNv3 backward -- replaces DCNv3.dcnv3_backward (network/ops_dcnv3/src/dcnv3.h:40-59 -> cuda/dcnv3_cuda.cu:87-174 ->
+ * cuda/dcnv3_im2col_cuda.cuh:386-487 + :82-140).  grad_out (N,Ho,Wo,G*D) `dtype`; grad_in (N,H,W,G*D), grad_offset
+ * (offset_numel), grad_mask (mask_numel) are OPMATH typed like the reference's (float for GP_F16 / GP_F32, double for
+ * GP_F64; dcnv3_cuda.cu:123-130) and are zero-filled here before the accumulation, so the tail of an offset buffer
+ * longer than the consumed prefix stays zero.  grad_in is accumulated with atomics (run-to-run rounding differences in
+ * the last bits, as in the reference); grad_offset / grad_mask have one writer per element. */
+int gp_dcnv3_backward(const void* in, const void* offset, const void* mask, const void* grad_out, void* grad_in,
+                      void* grad_offset, void* grad_mask, long offset_numel, long mask_numel, int N, int H, int W, int G,
+                      int D, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                      int dilation_h, int dilation_w, float offset_scale, int remove_center, int im2col_step,
+                      int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused GEMM / implicit-GEMM convolution on MFMA.

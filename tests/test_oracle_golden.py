@@ -114,3 +114,27 @@ def test_map_transformer(golden):
     z = golden("map_transformer")
     P = O.load_params(synth.synth_state_dict(PoseNetConfig(nocsmap_encoder="att"), 0))
     assert np.abs(O.map_transformer_ref(P, T(z["x"])).numpy() - z["expected"]).max() < 2e-5
+
+
+def _geom(z):
+    kh, kw, sh, sw, ph, pw, dh, dw, G, D, rc = (int(v) for v in z["params"])
+    return (kh, kw, sh, sw, ph, pw, dh, dw, G, D, float(z["offset_scale"]), rc)
+
+
+@pytest.mark.parametrize("name", ["dcnv3_any_fwd_ref", "dcnv3_any_fwd_hw", "dcnv3_any_fwd_dil_rc"])
+def test_dcnv3_any_forward_oracle(golden, name):
+    """Generic-geometry fp64 forward (C restatement of cuh:216-282) vs the reference's dcnv3_core_pytorch."""
+    from oracle.dcnv3_c import dcnv3_forward_any_c
+    z = golden(name)
+    got = dcnv3_forward_any_c(z["input"], z["offset"], z["mask"], *_geom(z))
+    assert np.abs(got - z["expected"]).max() < 1e-6       # dcnv3_core_pytorch builds its grid from fp32 linspace
+
+
+@pytest.mark.parametrize("name", ["dcnv3_any_bwd_D1", "dcnv3_any_bwd_D16", "dcnv3_any_bwd_D30", "dcnv3_any_bwd_hw"])
+def test_dcnv3_any_backward_oracle(golden, name):
+    """fp64 backward (C restatement of cuh:386-487 / :82-140) vs autograd through the reference's dcnv3_core_pytorch."""
+    from oracle.dcnv3_c import dcnv3_backward_any_c
+    z = golden(name)
+    gi, go, gm = dcnv3_backward_any_c(z["input"], z["offset"], z["mask"], z["grad_output"], *_geom(z))
+    for got, key in ((gi, "grad_input"), (go, "grad_offset"), (gm, "grad_mask")):
+        assert np.abs(got - z[key]).max() < 1e-6 * max(1.0, np.abs(z[key]).max()), key
