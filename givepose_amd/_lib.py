@@ -65,6 +65,12 @@ PROTOTYPES = {
     "gp_mask_resize_nearest": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "gp_crop_rois": ([_P] * 12 + [c_int] * 7 + [_P], c_int),
     "gp_pred_rt": ([_P] * 6 + [c_int, _P], c_int),
+    "gp_sn_stem": ([_P] * 4 + [c_int] * 3 + [_P], c_int),
+    "gp_sn_pointwise": ([_P] * 6 + [c_long] + [c_int] * 4 + [_P], c_int),
+    "gp_sn_depthwise": ([_P] * 4 + [c_int] * 7 + [_P], c_int),
+    "gp_sn_avgpool": ([_P] * 2 + [c_int] * 3 + [_P], c_int),
+    "gp_sn_se": ([_P] * 6 + [c_int] * 3 + [_P], c_int),
+    "gp_sn_head": ([_P] * 12 + [c_int] * 5 + [_P], c_int),
     "gp_graph_begin": ([_P], c_int),
     "gp_graph_end": ([_P, POINTER(c_void_p)], c_int),
     "gp_graph_launch": ([_P, _P], c_int),
@@ -104,3 +110,11 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().gp_last_error()
         raise GivePoseHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+_capturing = 0
+
+
+def capturing():
+    """True between gp_graph_begin and gp_graph_end of this process (raw hipStreamBeginCapture: torch does not see it)."""
+    return _capturing > 0

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libgivepose_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "mlp.hip", "dcnv3.hip", "dcnv3_any.hip", "norm.hip", "misc.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "mlp.hip", "dcnv3.hip", "dcnv3_any.hip", "norm.hip", "misc.hip", "scalenet.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 

@@ -54,15 +54,21 @@ def _contig(t, name):
 
 # ----------------------------------------------------------------------------------- GEMM / conv
 _WS = {}
+_WS_RETIRED = []      # outgrown workspaces: a captured hipGraph may have their address baked in, so they are never freed
 
 
 def _workspace(device, nfloats):
-    """Split-K partial-sum workspace of the CURRENT stream: launches on different streams must not share one."""
+    """Split-K partial-sum workspace of the CURRENT stream: launches on different streams must not share one.  A
+    workspace is only ever replaced by a larger one, and the old tensor is kept alive (an earlier hipGraph of that stream
+    still points at it).  No allocation may happen while a hipGraph is being captured (the capture is raw HIP, which
+    PyTorch's allocator does not know about): the eager warm-up pass in front of every capture sizes the workspace."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nfloats:
-        if ws is not None and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("split-K workspace too small during graph capture")
+        if _lib.capturing():
+            raise RuntimeError("split-K workspace allocation during hipGraph capture (run the same shapes eagerly once first)")
+        if ws is not None:
+            _WS_RETIRED.append(ws)
         ws = torch.empty(max(nfloats, 1 << 24), dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws

@@ -76,16 +76,35 @@ class PoseNet(nn.Module):
         self.eval()
 
     # ------------------------------------------------------------------ weights
-    def load_state_dict(self, state_dict, strict=True):
-        r = super().load_state_dict(state_dict, strict=strict)
+    def _reset_plans(self):
+        """Drop the packed weights and every plan (buffers + hipGraph).  Work of any slot stream may still be in flight on
+        buffers that are about to return to the allocator, and a graph exec holds raw pointers into them: synchronise the
+        device first, destroy the graph execs, then let the tensors go."""
+        if getattr(self, "_plans", None):
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            lib = _lib.load()
+            for plan in self._plans.values():
+                if plan.get("graph") is not None:
+                    lib.gp_graph_destroy(plan["graph"])
+                    plan["graph"] = None
         self._packed = None
         self._plans = {}
+
+    def __del__(self):
+        try:
+            self._reset_plans()
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self._reset_plans()
         return r
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._packed = None
-        self._plans = {}
+        self._reset_plans()
         return r
 
     @torch.no_grad()
@@ -477,8 +496,6 @@ class PoseNet(nn.Module):
         if self._packed is None:
             self._pack(device)
         B = data["roi_img"].shape[0]
-        plan = self._plan(B, device, slot)
-        buf = plan["buf"]
         cur = torch.cuda.current_stream()
         if self.use_graph:
             # hipGraph capture is not permitted on the legacy default stream: the graph path owns a stream (per slot)
@@ -489,18 +506,24 @@ class PoseNet(nn.Module):
         else:
             run_stream = cur
         with torch.cuda.stream(run_stream):
+            plan = self._plan(B, device, slot)          # a new plan's buffers belong to the stream that will use them
+            buf = plan["buf"]
             for k in self._INPUT_KEYS:
                 src = data[k]
                 if src.data_ptr() != buf[k].data_ptr():
                     buf[k].copy_(src.reshape(buf[k].shape), non_blocking=True)
+                    if src.is_cuda and run_stream is not cur:
+                        src.record_stream(run_stream)   # the caller may free `src` while this copy is still queued
             if self.use_graph and plan["warm"]:
                 lib = _lib.load()
                 sp = ctypes.c_void_p(run_stream.cuda_stream)
                 if plan["graph"] is None:
                     _lib.check(lib.gp_graph_begin(sp), "gp_graph_begin")
+                    _lib._capturing += 1
                     try:
                         self._launch_all(B, plan)
                     finally:
+                        _lib._capturing -= 1
                         ge = ctypes.c_void_p()
                         rc = lib.gp_graph_end(sp, ctypes.byref(ge))
                     _lib.check(rc, "gp_graph_end")

@@ -263,3 +263,71 @@ def synth_batch(B: int, seed: int = 0, img_size: int = 256, out_res: int = 64):
     d["resize_ratio"] = (out_res / scale).astype(np.float32)     # load_data_eval.py:267,331
     d["mean_size"] = MEAN_SIZES[r.integers(0, 6, B)]
     return d
+
+
+# ------------------------------------------------------------------------------------------------- Scale_net
+# torchvision 0.15.2 mobilenet_v3_small "features" (third-party arithmetic, restated from the MobileNetV3 paper /
+# torchvision's inverted-residual settings -- UNPINNED: torchvision is not installed here):
+#   (in, kernel, expanded, out, squeeze-excitation, activation, stride)
+MBV3S = ((16, 3, 16, 16, True, "RE", 2), (16, 3, 72, 24, False, "RE", 2), (24, 3, 88, 24, False, "RE", 1),
+         (24, 5, 96, 40, True, "HS", 2), (40, 5, 240, 40, True, "HS", 1), (40, 5, 240, 40, True, "HS", 1),
+         (40, 5, 120, 48, True, "HS", 1), (48, 5, 144, 48, True, "HS", 1), (48, 5, 288, 96, True, "HS", 2),
+         (96, 5, 576, 96, True, "HS", 1), (96, 5, 576, 96, True, "HS", 1))
+MBV3S_LAST = 576
+
+
+def make_divisible(v, divisor=8):
+    """torchvision.ops.misc / _utils._make_divisible: squeeze channels of the SE block = make_divisible(expanded // 4, 8)."""
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def scale_net_manifest(feat_dim=24, cats_num=6, use_hw=True):
+    """state_dict names / shapes of the reference ``Scale_net`` (network/scale_net.py:22-43): two
+    nn.Sequential(mobilenet_v3_small.features, avgpool, Flatten) encoders + line1..3.  The torchvision key layout
+    (features.{i}.block.{j}.{0,1} = conv / BatchNorm, SqueezeExcitation fc1 / fc2) is from memory."""
+    m = OrderedDict()
+    for enc in ("feat_encoder_bbox", "feat_encoder_full"):
+        f = enc + ".0"
+        m[f + ".0.0.weight"] = (16, 3, 3, 3)
+        _bn_manifest(f + ".0.1", 16, m)
+        for i, (cin, k, exp, cout, se, _, _) in enumerate(MBV3S, 1):
+            j = 0
+            if exp != cin:
+                m[f"{f}.{i}.block.{j}.0.weight"] = (exp, cin, 1, 1)
+                _bn_manifest(f"{f}.{i}.block.{j}.1", exp, m)
+                j += 1
+            m[f"{f}.{i}.block.{j}.0.weight"] = (exp, 1, k, k)
+            _bn_manifest(f"{f}.{i}.block.{j}.1", exp, m)
+            j += 1
+            if se:
+                sq = make_divisible(exp // 4, 8)
+                m[f"{f}.{i}.block.{j}.fc1.weight"] = (sq, exp, 1, 1)
+                m[f"{f}.{i}.block.{j}.fc1.bias"] = (sq,)
+                m[f"{f}.{i}.block.{j}.fc2.weight"] = (exp, sq, 1, 1)
+                m[f"{f}.{i}.block.{j}.fc2.bias"] = (exp,)
+                j += 1
+            m[f"{f}.{i}.block.{j}.0.weight"] = (cout, exp, 1, 1)
+            _bn_manifest(f"{f}.{i}.block.{j}.1", cout, m)
+        m[f + ".12.0.weight"] = (MBV3S_LAST, 96, 1, 1)
+        _bn_manifest(f + ".12.1", MBV3S_LAST, m)
+    m["line1.weight"], m["line1.bias"] = (128, 2 * MBV3S_LAST), (128,)
+    m["line2.weight"], m["line2.bias"] = (feat_dim, 128 + cats_num), (feat_dim,)
+    m["line3.weight"], m["line3.bias"] = (1, feat_dim + (2 if use_hw else 0) + cats_num), (1,)
+    return m
+
+
+def synth_scale_net_state_dict(feat_dim=24, seed=0):
+    return OrderedDict((k, synth_tensor("scale_net." + k, s, seed)) for k, s in scale_net_manifest(feat_dim).items())
+
+
+def synth_scale_batch(B, seed=0, img_size=256):
+    """Extra eval-loader keys Scale_net reads (evaluation/load_data_eval.py:336-361, evaluate.py:101-102)."""
+    r = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, 0x5CA1E]))
+    d = synth_batch(B, seed, img_size)
+    d["full_img"] = np.broadcast_to(r.standard_normal((1, 3, img_size, img_size), dtype=np.float32), (B, 3, img_size, img_size)).copy()
+    cat = r.integers(0, 6, B)
+    d["one_hot"] = np.eye(6, dtype=np.float32)[cat]
+    return d

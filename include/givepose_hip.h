@@ -278,6 +278,28 @@ int gp_graph_end(void* stream, void** graph_exec_out);
 int gp_graph_launch(void* graph_exec, void* stream);
 int gp_graph_destroy(void* graph_exec);
 
+/* ---------------------------------------------------------------------------------------------
+ * Scale_net (network/scale_net.py:22-65; called before PoseNet at evaluation/evaluate.py:111-113) -- fp32, channels-last.
+ * Each entry replaces the ATen calls of one torchvision mobilenet_v3_small building block (third-party, 0.15.2) with eval
+ * BatchNorm folded into the weights by the host; act: 0 none, 1 ReLU, 2 Hardswish.
+ *   gp_sn_stem      features[0]: Conv2d(3,16,3,s2,p1)+BN+Hardswish; img (B,3,H,W) NCHW, w (27,16) k = ci*9+kh*3+kw -> y (B,H/2,W/2,16)
+ *   gp_sn_pointwise Conv2d 1x1 (+BN) (+act) (+residual); x (M,K) rows optionally scaled by the SqueezeExcitation gate se (M/HW, K)
+ *   gp_sn_depthwise Conv2d kxk groups=C stride s pad k/2 (+BN) + act; w tap-major (k*k, C)
+ *   gp_sn_avgpool   AdaptiveAvgPool2d(1): (B,HW,C) -> (B,C)
+ *   gp_sn_se        SqueezeExcitation gate: hardsigmoid(fc2(relu(fc1(pooled)))) -> (B,C)
+ *   gp_sn_head      scale_net.py:53-65: line1/ReLU/cat(one_hot)/line2/ReLU/cat(one_hot)/cat(roi_wh/100)/line3 + ||mean_size|| -> (B) */
+int gp_sn_stem(const float* img, const float* w, const float* b, float* y, int B, int H, int W, void* stream);
+int gp_sn_pointwise(const float* x, const float* w, const float* bias, const float* se, const float* residual, float* y, long M,
+                    int N, int K, int HW, int act, void* stream);
+int gp_sn_depthwise(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int KS, int stride,
+                    int act, void* stream);
+int gp_sn_avgpool(const float* x, float* y, int B, int HW, int C, void* stream);
+int gp_sn_se(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* scale, int B, int C,
+             int S, void* stream);
+int gp_sn_head(const float* feat_roi, const float* feat_full, const float* one_hot, const float* roi_wh, const float* mean_size,
+               const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, float* scale,
+               int B, int F, int feat_dim, int cats_num, int use_hw, void* stream);
+
 /* ---- per-launch HIP-event timing (bench.py roofline leg).  Between begin/end every gp_* launch on
  * `stream` is bracketed by hipEvents; gp_timing_report fills, per kernel class (GP_KC_*), launches,
  * total ms, algorithmic flops and bytes. */

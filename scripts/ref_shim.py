@@ -312,6 +312,70 @@ class _Resize(nn.Module):
         return F.interpolate(img, size=tuple(self.size), mode="nearest")
 
 
+class _ConvBNAct(nn.Sequential):
+    """torchvision.ops.misc.Conv2dNormActivation: [Conv2d(bias=False), BatchNorm2d(eps 1e-3, momentum 1e-2), act] [memory]."""
+
+    def __init__(self, cin, cout, k=1, stride=1, groups=1, act=None):
+        layers = [nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False), nn.BatchNorm2d(cout, eps=1e-3, momentum=1e-2)]
+        if act is not None:
+            layers.append(act())
+        super().__init__(*layers)
+        self.out_channels = cout
+
+
+class _SqueezeExcitation(nn.Module):
+    """torchvision.ops.misc.SqueezeExcitation(activation=ReLU, scale_activation=Hardsigmoid) [memory]."""
+
+    def __init__(self, c, sq):
+        super().__init__()
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc1, self.fc2 = nn.Conv2d(c, sq, 1), nn.Conv2d(sq, c, 1)
+        self.activation, self.scale_activation = nn.ReLU(), nn.Hardsigmoid()
+
+    def forward(self, x):
+        return x * self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
+
+
+class _InvertedResidual(nn.Module):
+    """torchvision.models.mobilenetv3.InvertedResidual [memory]."""
+
+    def __init__(self, cin, k, exp, cout, se, act, stride):
+        super().__init__()
+        from givepose_amd.synth import make_divisible
+        A = nn.Hardswish if act == "HS" else nn.ReLU
+        layers = []
+        if exp != cin:
+            layers.append(_ConvBNAct(cin, exp, 1, act=A))
+        layers.append(_ConvBNAct(exp, exp, k, stride, groups=exp, act=A))
+        if se:
+            layers.append(_SqueezeExcitation(exp, make_divisible(exp // 4, 8)))
+        layers.append(_ConvBNAct(exp, cout, 1, act=None))
+        self.block = nn.Sequential(*layers)
+        self.use_res_connect = stride == 1 and cin == cout
+
+    def forward(self, x):
+        y = self.block(x)
+        return x + y if self.use_res_connect else y
+
+
+class _MobileNetV3Small(nn.Module):
+    """Stand-in for torchvision.models.mobilenet_v3_small (0.15.2), restated from memory / the MobileNetV3 paper: only
+    ``features`` and ``avgpool`` are used by network/scale_net.py:25-29.  Pins the Scale_net WIRING, not torchvision."""
+
+    def __init__(self):
+        super().__init__()
+        from givepose_amd.synth import MBV3S, MBV3S_LAST
+        layers = [_ConvBNAct(3, 16, 3, 2, act=nn.Hardswish)]
+        layers += [_InvertedResidual(*cfg) for cfg in MBV3S]
+        layers.append(_ConvBNAct(96, MBV3S_LAST, 1, act=nn.Hardswish))
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+
+
+def _mobilenet_v3_small(pretrained=False, **kw):
+    return _MobileNetV3Small()
+
+
 # --------------------------------------------------------------------------- transforms3d
 def _axangle2mat(axis, angle, is_normalized=False):
     x, y, z = axis
@@ -376,6 +440,8 @@ def _populate(m):
         m._cfg = lambda **k: {}
     elif n == "timm":
         m.create_model = _timm_create_model
+    elif n == "torchvision.models":
+        m.mobilenet_v3_small = _mobilenet_v3_small
     elif n == "torchvision.transforms":
         m.Resize = _Resize
         m.InterpolationMode = _InterpolationMode
