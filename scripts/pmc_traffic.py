@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into per-kernel-class HBM traffic.
 
-  python scripts/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out.json> [steps profiled]
+  python scripts/pmc_traffic.py <dir with the FETCH_SIZE pass> <dir with the WRITE_SIZE pass> <out.json> [steps profiled] [commit]
 
 (steps profiled = forward passes each rocprofv3 run executed, e.g. 4 for bench.py --steps 2 --warmup 1 --no-graph
 --no-roofline --no-cpu-baseline --inflight 1: max(warmup, 2) + steps; gives hbm_bytes_per_step)
@@ -11,7 +11,7 @@ requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled 
 """
 import collections, csv, glob, json, sys
 
-CLASS = (("gemm", ("gemm_big_kernel", "gemm_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
+CLASS = (("gemm", ("gemm_big_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
          ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
          ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
          ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
@@ -42,7 +42,8 @@ for cls, _ in CLASS:
         wb = wr[cls][1] * 1024 / wr[cls][0]
         res[cls] = {"launches_profiled": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb,
                     "hbm_bytes_per_launch": rd + wb, "hbm_bytes_per_step": (rd + wb) * n / steps}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline --inflight 1, bs=64 fp16",
+commit = sys.argv[5] if len(sys.argv) > 5 else "unknown"
+json.dump({"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline --no-parity --no-h2d --inflight 1, bs=64 fp16",
            "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "classes": res},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -20,13 +20,24 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef MTN
+#define MTN 4
+#endif
+#ifndef VPXT
+#define VPXT 8
+#endif
 #ifndef ACC0
 #define ACC0 0.f      /* -DACC0=1e30f: if the victim's wrong values become huge, accumulator data of the aggressor leaks into it */
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 
 // ------------------------------------------------------------------------------------------------ aggressor
-__global__ __launch_bounds__(256, 2) void aggressor(const half_t* __restrict__ X, const half_t* __restrict__ W, half_t* __restrict__ C,
+#ifdef LB1
+#define AGG_LB __launch_bounds__(256)
+#else
+#define AGG_LB __launch_bounds__(256, 2)
+#endif
+__global__ AGG_LB void aggressor(const half_t* __restrict__ X, const half_t* __restrict__ W, half_t* __restrict__ C,
                                                     int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void aggressor(const half_t* __restrict__ X
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MTN; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&wf[nt]), *reinterpret_cast<const half8*>(&xf[mt]),
                                                                          acc[nt][mt], 0, 0, 0);
         }
@@ -87,11 +98,15 @@ __global__ __launch_bounds__(256, 2) void aggressor(const half_t* __restrict__ X
     int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = kt + 1 < nkt;
+#ifndef NOLOADS
         if (more) gload(kt + 1);
+#endif
 #ifndef NOMFMA
         compute(buf);
 #endif
+#ifndef NOLOADS
         if (more) sstore(buf ^ 1);
+#endif
         __syncthreads();
         buf ^= 1;
     }
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void aggressor(const half_t* __restrict__ X
 // ------------------------------------------------------------------------------------------------ victim
 __global__ __launch_bounds__(256) void victim(const float* __restrict__ xyz4, const float* __restrict__ w, const float* __restrict__ bias,
                                               half_t* __restrict__ y, long rows, int Cout) {
-    constexpr int VEC = 8, PXT = 8;
+    constexpr int VEC = 8, PXT = VPXT;
     const int CT = Cout / VEC, PG = 256 / CT;
     const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
     float w0[VEC], w1[VEC], w2[VEC], bv[VEC];
@@ -167,7 +182,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&ax, (long)M * K * 2)); CK(hipMalloc(&aw, (long)N * K * 2)); CK(hipMalloc(&ac, (long)M * N * 2)); CK(hipMalloc(&cnt, 4 * NV));
     fill_f32<<<(R * 4 + 255) / 256, 256>>>(xyz4, R * 4, 1); fill_f32<<<3, 256>>>(w, CO * 3, 2); fill_f32<<<1, 256>>>(b, CO, 3);
     fill_f16<<<((long)M * K + 255) / 256, 256>>>(ax, (long)M * K, 4, 1.f); fill_f16<<<((long)N * K + 255) / 256, 256>>>(aw, (long)N * K, 5, 0.01f);
-    const int vgrid = (int)(R / 64);
+    const int vgrid = (int)(R / (8 * VPXT));
     victim<<<vgrid, 256>>>(xyz4, w, b, ref, R, CO);
     CK(hipDeviceSynchronize());
     hipStream_t sa, sb;
