@@ -3,8 +3,12 @@
 Stream A loops an AGGRESSOR launch, stream B loops a VICTIM launch into rotating output buffers; after every round the
 victim outputs are compared bitwise with a reference computed alone.  Nothing is shared between the two streams.
 
-  AGG = v1 | v7 | v1small | torchmm | none     (gp_gemm variant 1 / 7 on the PnP fc1 shape, or stock torch.mm)
-  VIC = k3 | torchfma | gn                      (gp_pointwise_k3 / stock torch elementwise / gp_groupnorm_stats)
+  AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | mlp | torchmm | none
+  VIC = k3 | gnapply | gn | torchfma            (GP_K3_NOPK=1: the victim with scalar FMAs)
+The v1* aggressors are the round-1 register-staged `gemm_kernel`, which no longer exists in the library: run them
+against a build of the round-1 sources (git show 35dfc42:givepose_amd/csrc/<file> for the six .hip files + common.hpp,
+hipcc -O3 --offload-arch=gfx950 -fPIC -shared) with GP_LIB_PATH=<that .so>; scripts/repro/pkfma_beside_mfma.hip is the
+self-contained form.  Results of round 2: profiles/r02_race3...6.log.
 """
 import os
 import sys

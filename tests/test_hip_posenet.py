@@ -89,6 +89,31 @@ def test_fp32_matches_oracle_other_batch(net32):
     assert torch.equal(out["mask"].cpu(), ref["mask"])
 
 
+@pytest.mark.parametrize("B", [2, 3, 6, 7, 9])
+def test_fp32_matches_oracle_batch_sweep(net32, B):
+    """Batch sizes evaluate.py really feeds (the detections of one frame): every remainder of B mod 4 moves the DCNv3
+    quarter-buffer coupling (crop b reads the offset rows of crop b // 4) and the npre prefix."""
+    from givepose_amd import synth
+    from givepose_amd.config import PoseNetConfig
+    from oracle import posenet_ref as O
+    data = _batch(B, 900 + B)
+    ref = O.posenet_forward_ref(O.load_params(synth.synth_state_dict(PoseNetConfig(), 0)), data, PoseNetConfig())
+    out = net32(data, "cuda")
+    for k, tol in (("rot", 1e-4), ("trans", 1e-4), ("size", 1e-4), ("nocs_coor", 2e-4), ("ivfc_coor", 2e-4)):
+        assert float((out[k].cpu() - ref[k]).abs().max()) < tol, (B, k)
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
+
+
+def test_batch_above_im2col_step_must_be_a_multiple_like_the_reference():
+    """dcnv3_cuda.cu:46-49: batch % min(batch, im2col_step = 256) == 0 or the op refuses (257 crops -> error, not garbage)."""
+    from givepose_amd import _lib, ops
+    x = torch.zeros(257, 4, 4, 256, device="cuda", dtype=torch.float16)
+    off = torch.zeros(257, 4, 4, 72, device="cuda", dtype=torch.float16)
+    msk = torch.zeros(257, 4, 4, 36, device="cuda", dtype=torch.float16)
+    with pytest.raises(_lib.GivePoseHipError, match="must divide im2col_step"):
+        ops.dcnv3_forward(x, off, msk, 3, 3, 2, 2, 1, 1, 1, 1, 4, 64, 1.0, 256)
+
+
 @pytest.fixture(scope="module")
 def oracle64():
     """The oracle on the bench shape (64 crops; crop b reads the offset rows of crop b // 4, npre = nq + r + 8 rows of the
