@@ -109,12 +109,14 @@ class PoseNet(nn.Module):
 
     @torch.no_grad()
     def _pack(self, device):
-        """Reference-layout fp32 state dict -> kernel-layout device tensors (done once)."""
-        sd = {k: v.detach().to(device=device, dtype=torch.float32) if v.is_floating_point() else v
+        """Reference-layout fp32 state dict -> kernel-layout device tensors (done once).  Every fold (eval BatchNorm into
+        a conv, conv1x1 into input_proj, LayerNorm affine into fc1) and every rounding to the storage type happens on the
+        HOST; the device only ever runs this library's kernels (the one device-side step is gp_convnext_mlp_pack_w2)."""
+        sd = {k: v.detach().to(device="cpu", dtype=torch.float32) if v.is_floating_point() else v.detach().cpu()
               for k, v in self.state_dict().items()}
         T = self.compute_dtype
-        f32 = lambda t: t.contiguous().float()
-        lowp = lambda t: t.contiguous().to(T)
+        f32 = lambda t: t.contiguous().float().to(device)
+        lowp = lambda t: t.contiguous().to(T).to(device)
         W = {}
         cfg = self.cfg
         g = lambda k: sd["backbone." + k]
@@ -154,8 +156,9 @@ class PoseNet(nn.Module):
                     W[q + "fc2_wp"] = ops.convnext_mlp_pack_w2(W[q + "fc2_w"])
                 if T == torch.float16 and d == 512 and cfg.defer_ln:   # LayerNorm folded into fc1's epilogue
                     w1, lw, lb = g(p + "mlp.fc1.weight"), g(p + "norm.weight"), g(p + "norm.bias")
-                    W[q + "fc1_wg"] = lowp(w1 * lw[None, :])
-                    W[q + "fc1_cs"] = f32(W[q + "fc1_wg"].float().sum(1))          # column sums of the ROUNDED weights
+                    wg = (w1 * lw[None, :]).to(T)
+                    W[q + "fc1_wg"] = lowp(wg)
+                    W[q + "fc1_cs"] = f32(wg.float().sum(1))                          # column sums of the ROUNDED weights
                     W[q + "fc1_cb"] = f32(w1 @ lb + g(p + "mlp.fc1.bias"))
         for head in ("xyz_nocs_head", "xyz_deform_head"):
             h = lambda k: sd[f"{head}.{k}"]
@@ -174,7 +177,7 @@ class PoseNet(nn.Module):
             a = lambda k: sd["nocs_encoder." + k]
             W["att.pe_w"] = lowp(a("patch_embed.proj.weight").permute(0, 2, 3, 1).reshape(256, -1))   # K = (ky,kx,c)
             W["att.pe_b"] = f32(a("patch_embed.proj.bias"))
-            W["att.pos"] = a("pos_embed").reshape(64, 256)                                           # tiled per batch in _plan
+            W["att.pos"] = f32(a("pos_embed").reshape(64, 256))                                      # tiled per batch in _plan
             W["att.ones"] = torch.ones(256, dtype=torch.float32, device=device)
             W["att.norm_w"], W["att.norm_b"] = f32(a("norm.weight")), f32(a("norm.bias"))
             for i in range(3):

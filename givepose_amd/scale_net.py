@@ -52,7 +52,8 @@ class Scale_net(nn.Module):
     @torch.no_grad()
     def _pack(self, device):
         """Fold eval BatchNorm (eps 1e-3) into the convolutions and lay the weights out for csrc/scalenet.hip."""
-        sd = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in self.state_dict().items() if v.is_floating_point()}
+        sd = {k: v.detach().to(device="cpu", dtype=torch.float32) for k, v in self.state_dict().items() if v.is_floating_point()}   # folds on the host
+        dev = lambda t: t.contiguous().to(device)
 
         def fold(conv, bn):
             sc = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-3)
@@ -62,32 +63,32 @@ class Scale_net(nn.Module):
         for enc in ("feat_encoder_bbox", "feat_encoder_full"):
             f, E = enc + ".0", {}
             w, b = fold(f + ".0.0", f + ".0.1")
-            E["stem"] = (w.reshape(16, 27).t().contiguous(), b.contiguous())
+            E["stem"] = (dev(w.reshape(16, 27).t()), dev(b))
             blocks = []
             for i, (cin, k, exp, cout, se, act, stride) in enumerate(synth.MBV3S, 1):
                 j, blk = 0, {"cfg": (cin, k, exp, cout, se, _ACT[act], stride)}
                 if exp != cin:
                     w, b = fold(f"{f}.{i}.block.{j}.0", f"{f}.{i}.block.{j}.1")
-                    blk["expand"] = (w.reshape(exp, cin).contiguous(), b.contiguous())
+                    blk["expand"] = (dev(w.reshape(exp, cin)), dev(b))
                     j += 1
                 w, b = fold(f"{f}.{i}.block.{j}.0", f"{f}.{i}.block.{j}.1")
-                blk["dw"] = (w.reshape(exp, k * k).t().contiguous(), b.contiguous())
+                blk["dw"] = (dev(w.reshape(exp, k * k).t()), dev(b))
                 j += 1
                 if se:
                     q = f"{f}.{i}.block.{j}."
                     sq = sd[q + "fc1.weight"].shape[0]
-                    blk["se"] = (sd[q + "fc1.weight"].reshape(sq, exp).contiguous(), sd[q + "fc1.bias"].contiguous(),
-                                 sd[q + "fc2.weight"].reshape(exp, sq).contiguous(), sd[q + "fc2.bias"].contiguous(), sq)
+                    blk["se"] = (dev(sd[q + "fc1.weight"].reshape(sq, exp)), dev(sd[q + "fc1.bias"]),
+                                 dev(sd[q + "fc2.weight"].reshape(exp, sq)), dev(sd[q + "fc2.bias"]), sq)
                     j += 1
                 w, b = fold(f"{f}.{i}.block.{j}.0", f"{f}.{i}.block.{j}.1")
-                blk["project"] = (w.reshape(cout, exp).contiguous(), b.contiguous())
+                blk["project"] = (dev(w.reshape(cout, exp)), dev(b))
                 blocks.append(blk)
             E["blocks"] = blocks
             w, b = fold(f + ".12.0", f + ".12.1")
-            E["last"] = (w.reshape(synth.MBV3S_LAST, 96).contiguous(), b.contiguous())
+            E["last"] = (dev(w.reshape(synth.MBV3S_LAST, 96)), dev(b))
             W[enc] = E
         for n in ("line1", "line2", "line3"):
-            W[n] = (sd[n + ".weight"].contiguous(), sd[n + ".bias"].contiguous())
+            W[n] = (dev(sd[n + ".weight"]), dev(sd[n + ".bias"]))
         self._packed = W
         return W
 
