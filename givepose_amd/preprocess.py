@@ -83,6 +83,8 @@ class RoiCropper:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("RoiCropper runs on a HIP device only (no CPU fallback)")
+        if self.device.index is None:            # "cuda" -> "cuda:<current>": tensors report an indexed device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         il, xl, yl = luts(im_H, im_W)
         self.img_lut = torch.from_numpy(il).to(self.device)
         self.xlut = torch.from_numpy(xl).to(self.device)
