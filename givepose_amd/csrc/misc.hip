@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void xyz_out_kernel(const T* __restrict__ x, c
 }
 
 // thread = one 16-B vector of output channels (its 3 x VEC weights + bias live in registers) x PXT pixels
-template <typename T, bool NOPK = false>
+template <typename T>
 __global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restrict__ xyz4, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ y,
                                                            long rows, int Cout) {
@@ -264,17 +264,7 @@ __global__ __launch_bounds__(256) void pointwise_k3_kernel(const float* __restri
         const f32x4 p = *reinterpret_cast<const f32x4*>(xyz4 + row * 4);
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            if constexpr (NOPK) {   // experiment arm (GP_K3_NOPK=1, scripts/race_min.py): scalar v_fma_f32, never packed
-                float t = bv[e];
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w2[e]), "v"(p[2]));
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w1[e]), "v"(p[1]));
-                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w0[e]), "v"(p[0]));
-                o.set(e, t);
-            } else {
-                o.set(e, fmaf(w0[e], p[0], fmaf(w1[e], p[1], fmaf(w2[e], p[2], bv[e]))));
-            }
-        }
+        for (int e = 0; e < VEC; ++e) o.set(e, fmaf(w0[e], p[0], fmaf(w1[e], p[1], fmaf(w2[e], p[2], bv[e]))));
         store16<T>(y + row * Cout + cs * VEC, o);
     }
 }
@@ -712,9 +702,7 @@ extern "C" int gp_pointwise_k3(const float* xyz4, const float* w, const float* b
     hipStream_t s = (hipStream_t)stream;
     const long total = cdiv(rows, (256 / (Cout / vec)) * 8) * 256;
     gp_timing_before(s, GP_KC_ELEMENTWISE, 6.0 * rows * Cout, rows * 16.0 + (double)rows * Cout * esz);
-    static const bool nopk = [] { const char* e = getenv("GP_K3_NOPK"); return e && e[0] == '1'; }();
-    if (dtype == GP_F16 && nopk) hipLaunchKernelGGL((pointwise_k3_kernel<half_t, true>), dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (half_t*)y, rows, Cout);
-    else if (dtype == GP_F16) hipLaunchKernelGGL(pointwise_k3_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (half_t*)y, rows, Cout);
+    if (dtype == GP_F16) hipLaunchKernelGGL(pointwise_k3_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (half_t*)y, rows, Cout);
     else hipLaunchKernelGGL(pointwise_k3_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, xyz4, w, b, (float*)y, rows, Cout);
     GP_LAUNCH_CHECK("gp_pointwise_k3");
 }

@@ -4,7 +4,8 @@ Stream A loops an AGGRESSOR launch, stream B loops a VICTIM launch into rotating
 victim outputs are compared bitwise with a reference computed alone.  Nothing is shared between the two streams.
 
   AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | mlp | torchmm | none
-  VIC = k3 | gnapply | gn | torchfma            (GP_K3_NOPK=1: the victim with scalar FMAs)
+  VIC = k3 | gnapply | gn | torchfma            (the scalar-FMA victim of r02_race6.log was a build switch of the investigation;
+                                                 scripts/repro/pkfma_beside_mfma.hip -DNOPK is its stand-alone form)
 The v1* aggressors are the round-1 register-staged `gemm_kernel`, which no longer exists in the library: run them
 against a build of the round-1 sources (git show 35dfc42:givepose_amd/csrc/<file> for the six .hip files + common.hpp,
 hipcc -O3 --offload-arch=gfx950 -fPIC -shared) with GP_LIB_PATH=<that .so>; scripts/repro/pkfma_beside_mfma.hip is the
