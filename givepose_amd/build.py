@@ -17,6 +17,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 # step (8 257 against 8 064 us of kernels, 10.16 against 10.4 k images/s).  The default build keeps them: the one
 # aggressor kernel is gone and the overlapped mode is clean in 4 650 stress slot-runs.  (The x86 host pass ignores the
 # unknown target feature with a warning.)
+FLAGS += os.environ.get("GP_EXTRA_HIPCC_FLAGS", "").split()   # investigation builds (e.g. -DGP_WREG_STAMPS), never the shipped library
 if os.environ.get("GP_NO_PACKED_FP32") == "1":
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wno-unknown-warning-option"]
 

@@ -1,5 +1,6 @@
 // Shared helpers for the givepose_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -87,6 +88,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 // instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the fc1 epilogues and the
 // GroupNorm+GELU passes VALU bound.  The fp32 storage path keeps gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) (bodies that need constexpr indices)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
     // erf(x / sqrt 2) = xc * r(xc^2), xc = clamp(x, +-4.4); r: degree-8 minimax (LP fit, weighted by the GELU error
     // x^2 / 2, constrained to meet erf at the clamp so that no second clamp is needed: beyond it the result is
@@ -110,28 +120,53 @@ __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
 }
 // the same polynomial on eight 2-vectors walked in lock step: eight independent dependency chains, so the packed FMAs
 // issue back to back instead of waiting out each other's latency (fused MLP kernel, csrc/mlp.hip)
-__device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) {
-    f32x2 xc[8], t[8], p[8];
+template <int NC>
+__device__ __forceinline__ void gelu_poly2_xn(f32x2* x) {
+    f32x2 xc[NC], t[NC], p[NC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) {
         xc[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -4.4f, 4.4f);
         xc[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -4.4f, 4.4f);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = xc[i] * xc[i];
+    for (int i = 0; i < NC; ++i) t[i] = xc[i] * xc[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(f32x2{6.9778819482e-11f, 6.9778819482e-11f}, t[i], f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
+    for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(f32x2{6.9778819482e-11f, 6.9778819482e-11f}, t[i], f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
     constexpr float cf[7] = {3.4381198132e-07f, -9.3718131897e-06f, 1.6778340171e-04f, -2.1052074914e-03f,
                              1.9270481587e-02f, -1.3212860816e-01f, 7.9751050727e-01f};
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{cf[k], cf[k]});
+        for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{cf[k], cf[k]});
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const f32x2 e = xc[i] * p[i];
         const f32x2 hx = x[i] * 0.5f;
         x[i] = __builtin_elementwise_fma(hx, e, hx);
+    }
+}
+__device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) { gelu_poly2_xn<8>(x); }
+// the same polynomial as 13 separable slices of one operation per element, for callers that hide it in the shadow of
+// MFMAs a slice at a time (gemm_wreg_kernel): slice S of chain c works on x[c] with the scratch xc[c], t[c], p[c].
+// Plain v_fma_f32 / v_mul_f32 from inline asm, NOT packed: beside MFMAs one v_pk_fma_f32 costs ~22 cycles more than two
+// v_fma_f32 (MI355X_MICROARCH.md, constants table), and hipcc packs whatever it can.  Same roundings as gelu_poly2
+// (IEEE fma / mul either way), so the results are bitwise those of the packed form.
+__device__ __forceinline__ float vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float vfma_s(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c)); return d; }
+__device__ __forceinline__ float vmul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+template <int S>
+__device__ __forceinline__ void gelu_poly2_slice(f32x2& x, f32x2& xc, f32x2& t, f32x2& p, float c1v) {
+    constexpr float cf[7] = {3.4381198132e-07f, -9.3718131897e-06f, 1.6778340171e-04f, -2.1052074914e-03f,
+                             1.9270481587e-02f, -1.3212860816e-01f, 7.9751050727e-01f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if constexpr (S == 0) xc[e] = __builtin_amdgcn_fmed3f(x[e], -4.4f, 4.4f);
+        else if constexpr (S == 1) t[e] = vmul(xc[e], xc[e]);
+        else if constexpr (S == 2) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(6.9778819482e-11f), "v"(t[e]), "v"(c1v)); p[e] = d; }   // c1v = -7.3778779375e-09f in a VGPR (one SGPR per VALU instruction)
+        else if constexpr (S >= 3 && S <= 9) p[e] = vfma_s(p[e], t[e], cf[S - 3 < 0 ? 0 : (S - 3 > 6 ? 6 : S - 3)]);
+        else if constexpr (S == 10) xc[e] = vmul(xc[e], p[e]);            // e
+        else if constexpr (S == 11) { float d; asm("v_mul_f32 %0, 0.5, %1" : "=v"(d) : "v"(x[e])); t[e] = d; }   // hx
+        else if constexpr (S == 12) x[e] = vfma(t[e], xc[e], t[e]);
     }
 }
 __device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }

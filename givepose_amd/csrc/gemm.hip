@@ -777,6 +777,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {   // s_waitcnt takes an imme
     }
 }
 
+__device__ __forceinline__ void wait_vmcnt_n(int n) {   // as wait_vmcnt for counts up to 24 (larger n waits for 24: stricter)
+#define GP_WV(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    switch (n) {
+        GP_WV(0) GP_WV(1) GP_WV(2) GP_WV(3) GP_WV(4) GP_WV(5) GP_WV(6) GP_WV(7) GP_WV(8) GP_WV(9) GP_WV(10) GP_WV(11) GP_WV(12)
+        GP_WV(13) GP_WV(14) GP_WV(15) GP_WV(16) GP_WV(17) GP_WV(18) GP_WV(19) GP_WV(20) GP_WV(21) GP_WV(22) GP_WV(23)
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    }
+#undef GP_WV
+}
+
 template <int WIMG, int NS>
 __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     constexpr int MT = 8, NT = 4, BM = 256, BN = 256, LEAD = NS - 2;
@@ -940,6 +950,231 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     }
 }
 
+// =====================================================================================================
+// Weights-in-registers GEMM for K = 512 (variant 16): C[M][N] = act(X[M][512] . W[N][512]^T + bias), fp16.
+// The tile kernels above move every operand byte through an LDS ring, and what a CU can pull from L2 (~53-70 GB/s) is
+// their wall: stage-2 fc1 (M 16384, N 2048, K 512) needs 1.57 MB per CU in 256 x 128 tiles.  With K = 512 a slice of
+// 256 output channels of W is 256 KB -- half of a CU's vector register file.  So a workgroup (8 waves, one per CU)
+// keeps ITS 256 rows of W in registers for the whole launch (a wave owns 32 rows = 32 A fragments = 128 VGPRs, loaded
+// once, straight from global memory in the MFMA layout) and streams a group of X rows past them: X tiles of 32 rows x
+// 1 KB go through a 4-buffer LDS ring by LDS-DMA (one instruction = one row, chunk-swizzled on the source side), every
+// wave reads the whole tile as B fragments (2 ds_read_b128 per 4 MFMAs).  Per CU: 256 KB + rows x 1 KB (0.77 MB at
+// 512 rows per group) and ONE barrier per 32 rows instead of one per K step.
+// Schedule (one period = one tile, one barrier): every wave runs the 64 MFMAs of tile q with the ACTIVATION of tile
+// q-1 in their shadow -- after each MFMA four plain v_fma_f32 / v_mul_f32 of the GELU polynomial (13 slices of one
+// operation per element, two chains per MFMA; inline asm, not packed: beside MFMAs a v_pk_fma_f32 costs ~22 cycles
+// more than two v_fma_f32) -- B fragments read two K steps ahead with counted lgkmcnt, the wave's four LDS-DMA
+// instructions of tile q+3 spread over the K steps (the two waves of a SIMD issue theirs two K steps apart), then the
+// four 8-byte stores of tile q-1.  sched_barriers pin that order (hipcc otherwise clusters the VALU work and waits
+// lgkmcnt(0) in front of every MFMA pair; sched_group_barrier pipelines did the same).
+// What bounds it (s_memtime stamps, scripts/wreg_stamps.py): the SIMD's vector ISSUE.  Per period and SIMD 128 MFMAs hold
+// the issue port 8 of their 16 cycles (1 024) and the GELU of 2 x 16 x 64 elements is 472 four-cycle instructions
+// (1 888): the MFMA + GELU block takes 3 400-3 600 of the period's ~4 100 cycles (the rest: stores, vmcnt wait,
+// barrier), so the matrix pipe cannot be more than ~58 % busy while the GELU shares the SIMD.  Measured (interleaved
+// medians, scripts/wreg_ab.py): 48.3 us against 47.5 (ping-pong tile) and 53.4 (256 x 128 tile) alone; end to end the
+// step gains 4 % serial and 0.7 % with three batches in flight, because a workgroup's H rows stay in the L2 of the XCD
+// that the following fc2 launch reads them from (fc2 49.6 -> 45.3 us).
+// Hazards: buffer (q+3)&3 was last read in period q-1, which every wave left through the barrier that opens period q
+// (WAR); a wave waits for ITS four DMA instructions of tile q+1 with a counted vmcnt right before the barrier that
+// closes period q, the barrier publishes all 32 rows (RAW).  vmcnt counts in issue order, loads and stores alike, so
+// the count is the number of vector-memory instructions the wave issued after the DMA of tile q+1: the DMA of tiles
+// q+2, q+3 and the stores of periods q-2, q-1, q (20 in the steady state) -- every store is ONE inline-asm instruction so
+// that the count is not the compiler's to change (nst() / ndma() below).
+template <int EPI, int ABL = 0>   // ABL: investigation builds: 1 no MFMA, 2 no stores, 4 no in-loop DMA, 8 no GELU shadow (wrong results, not
+                                 // instantiated), 16 time stamps (right results)
+__global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
+    constexpr int K = 512, KS = K / 32, TM = 32, NBUF = 4, BUFB = TM * K * 2, NT = 2, MT = 2;
+    static_assert(NT * MT * 2 == 8, "the epilogue walks eight 2-vectors");
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUFB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    // work item: all 8 N slices of an M group on one XCD (the X rows of the group enter one L2 only)
+    const int nsl = p.N >> 8;
+    const int bid = blockIdx.x;
+    int item;
+    {
+        const int per = gridDim.x >> 3;                          // host: gridDim.x % 8 == 0
+        item = (bid & 7) * per + (bid >> 3);                     // XCD-contiguous chunks of the (m group, n slice) list
+    }
+    const int mg = item / nsl, ns = item - mg * nsl;
+    const long m0 = (long)mg * p.tiles_m * TM;                   // tiles_m = tiles per M group
+    const int T = min(p.tiles_m, (int)((p.M - m0) / TM));
+    if (T <= 0) return;
+    const int nb = ns * 256 + wave * 32;
+
+    // ---- DMA: wave w fetches rows 4w .. 4w+3 of a tile; lane c fetches the 16-byte chunk c ^ (row & 15) of the row
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    const char* xsrc = reinterpret_cast<const char*>(p.X) + ((m0 + wave * 4) * (long)p.ldx) * 2;
+    const long rowb = (long)p.ldx * 2;
+    unsigned xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xoff[i] = (unsigned)(i * rowb) + ((lane ^ ((wave * 4 + i) & 15)) << 4);
+    auto dma = [&](int t) {
+        const char* src = xsrc + (long)t * TM * rowb;
+        const unsigned dst = lds0 + (t & (NBUF - 1)) * BUFB + wave * 4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_s(src, xoff[i], dst + i * 1024);
+    };
+    // B fragment (mt, ks) of a tile: row mt*16 + fr, chunk (ks*4 + fq) ^ fr = ((ks & 3)*4 ^ (fq ^ fr)) + (ks >> 2) * 16
+    unsigned boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = fr * 1024 + (((j * 4) ^ (fq ^ fr)) << 4);
+
+    uint4 wf[NT][KS];   // the resident W fragments (loaded below, after the first X tiles have been requested)
+    f32x4 b4[NT], acc[NT][MT];
+    f32x2 v[NT * MT * 2];   // pre-activation values of the previous tile
+    half_t* Cw = reinterpret_cast<half_t*>(p.C) + (m0 + fr) * (long)p.ldc + nb + fq * 4;
+    // B fragments of a tile are read two K steps ahead of their MFMAs into a ring of three register pairs; SHADOW: the
+    // GELU of the previous tile (v) is issued in the shadow of the MFMAs, two packed VALU operations behind each MFMA
+    // (13 slices x 4 chains per half tile: K steps 0-7 carry chains 0-3, K steps 8-15 chains 4-7).  sched_barriers pin
+    // the order: hipcc otherwise clusters the VALU work and waits lgkmcnt(0) in front of every MFMA pair.
+    f32x2 gx[4], gt[4], gp[4];
+    float c1v = -7.3778779375e-09f;
+    asm volatile("" : "+v"(c1v));   // a VGPR constant
+    auto mfmas = [&](int t, auto shadow, int tdma) {   // tdma: tile whose four DMA instructions ride along (< 0: none)
+        constexpr bool SH = decltype(shadow)::value && EPI == GP_EPI_GELU && !(ABL & 8);
+        const char* dsrc = xsrc + (long)tdma * TM * rowb;
+        const unsigned ddst = lds0 + (tdma & (NBUF - 1)) * BUFB + wave * 4 * 1024;
+        const char* xb = smem + (t & (NBUF - 1)) * BUFB;
+        uint4 bf[3][MT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                bf[ks][mt] = *reinterpret_cast<const uint4*>(xb + boff[ks & 3] + mt * 16 * 1024 + (ks >> 2) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (ks + 2 < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    bf[(ks + 2) % 3][mt] = *reinterpret_cast<const uint4*>(xb + boff[(ks + 2) & 3] + mt * 16 * 1024 + ((ks + 2) >> 2) * 256);
+            }
+            // the issuing wave stalls ~100 cycles per LDS-DMA instruction; the two waves of a SIMD (w, w + 4) issue theirs two
+            // K steps apart so that one of them keeps the SIMD busy
+            if constexpr (ks % 4 == 0) {
+                if (tdma >= 0 && wave >= 4) glds16_s(dsrc, xoff[ks / 4], ddst + (ks / 4) * 1024);
+            } else if constexpr (ks % 4 == 2) {
+                if (tdma >= 0 && wave < 4) glds16_s(dsrc, xoff[ks / 4], ddst + (ks / 4) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NT * MT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, nt = j / MT, mt = j % MT;
+                if constexpr (!(ABL & 1)) mma<half_t>(acc[nt][mt], wf[nt][ks], bf[ks % 3][mt]);
+                else acc[nt][mt][0] += __builtin_bit_cast(float, bf[ks % 3][mt].x ^ wf[nt][ks].x);
+                if constexpr (SH) {
+                    constexpr int half = ks / 8, slot = (ks % 8) * 2 + j / 2;      // slice index of this K step: two per K step
+                    constexpr int c0 = (j % 2) * 2;                                 // chains c0, c0 + 1
+                    if constexpr (slot < 13) {
+                        gelu_poly2_slice<slot>(v[half * 4 + c0], gx[c0], gt[c0], gp[c0], c1v);
+                        gelu_poly2_slice<slot>(v[half * 4 + c0 + 1], gx[c0 + 1], gt[c0 + 1], gp[c0 + 1], c1v);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    auto take = [&]() {   // accumulators -> v, accumulators back to the bias
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 a = acc[nt][mt];
+                acc[nt][mt] = b4[nt];
+                v[(mt * NT + nt) * 2] = f32x2{a[0], a[1]};
+                v[(mt * NT + nt) * 2 + 1] = f32x2{a[2], a[3]};
+            }
+    };
+    auto activate = [&]() {
+        if constexpr (EPI == GP_EPI_GELU) {
+            gelu_poly2_xn<4>(v);       // two rounds of four lock-step chains (register budget)
+            gelu_poly2_xn<4>(v + 4);
+        } else if constexpr (EPI == GP_EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{fmaxf(v[i][0], 0.0f), fmaxf(v[i][1], 0.0f)};
+        } else if constexpr (EPI == GP_EPI_LRELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{v[i][0] > 0.0f ? v[i][0] : 0.1f * v[i][0], v[i][1] > 0.0f ? v[i][1] : 0.1f * v[i][1]};
+        }
+    };
+    auto stores = [&](int t) {   // NT*MT stores of 8 bytes per lane, one instruction each (counted below)
+        half_t* c = Cw + (long)t * TM * p.ldc;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x2 lo = v[(mt * NT + nt) * 2], hi = v[(mt * NT + nt) * 2 + 1];
+                half4 o = {(half_t)lo[0], (half_t)lo[1], (half_t)hi[0], (half_t)hi[1]};
+                const half_t* dst = c + (long)mt * 16 * p.ldc + nt * 16;
+                if constexpr (!(ABL & 2)) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(o) : "memory");
+                else asm volatile("" ::"v"(dst), "v"(o));
+            }
+    };
+    // vector-memory instructions of this wave per period q: the DMA of tile q+3, then the stores of tile q-1
+    auto ndma = [&](int t) { return t < T && (!(ABL & 4) || t < 3) ? 4 : 0; };
+    auto nst = [&](int q) { return q >= 1 && !(ABL & 2) ? NT * MT : 0; };
+
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < T) dma(t);
+    // ---- W fragments: lane (fr, fq) of fragment (nt, ks) holds W[nb + nt*16 + fr][ks*32 + fq*8 .. +8]
+    const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + fr) * K + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt][ks] = *reinterpret_cast<const uint4*>(Wp + (long)nt * 16 * K + ks * 32);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        b4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + nt * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // everything in flight so far (three X tiles, W, bias) has landed before the loop starts.  The builtin, not inline
+    // asm: hipcc tracks it, and would otherwise wait for the W loads inside the loop (vmcnt(0) in every period)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b4[nt];
+    __builtin_amdgcn_s_barrier();
+    // ABL & 16: s_memtime stamps of workgroup 0 into p.ws: [wave][period][6] (scripts/wreg_stamps.py)
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(p.ws) + wave * 32 * 6;
+    auto mark = [&](int q, int k) {
+        if constexpr (ABL & 16) {
+            if (bid == 0) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) stamp[q * 6 + k] = t;
+            }
+        }
+    };
+    mark(0, 0);
+    // period 0: tile 0 has no predecessor to activate
+    mfmas(0, std::false_type{}, 3 < T && !(ABL & 4) ? 3 : -1);
+    take();
+    if (1 < T) wait_vmcnt_n(ndma(2) + ndma(3));
+    __builtin_amdgcn_s_barrier();
+    for (int q = 1; q < T; ++q) {
+        mark(q, 0);
+        mark(q, 1);
+        // the 64 MFMAs of tile q with the activation of tile q-1 in their shadow: per MFMA two VALU instructions, a
+        // ds_read_b128 every other one (two K steps ahead)
+        mfmas(q, std::true_type{}, q + 3 < T && !(ABL & 4) ? q + 3 : -1);
+        if constexpr (EPI != GP_EPI_GELU) activate();
+        __builtin_amdgcn_sched_barrier(0);
+        mark(q, 2);
+        stores(q - 1);
+        take();
+        __builtin_amdgcn_sched_barrier(0);
+        mark(q, 3);
+        if (!ABL && q >= 3 && q + 3 < T) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // steady state: 2 x 4 DMA + 3 x 4 stores
+        else if (q + 1 < T) wait_vmcnt_n(nst(q - 2) + ndma(q + 2) + nst(q - 1) + ndma(q + 3) + nst(q));
+        mark(q, 4);
+        __builtin_amdgcn_s_barrier();
+        mark(q, 5);
+    }
+    activate();
+    stores(T - 1);
+}
+
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
@@ -974,6 +1209,20 @@ static long pp_min_k() {   // shortest K that goes to the ping-pong kernel when 
                            // twice that for a launch that runs alone: measured end to end, bs 64 (K = 512: stage-2 fc1)
     static const long k = [] { const char* e = getenv("GP_PP_MIN_K"); return e ? atol(e) : 512l; }();
     return k;
+}
+
+static int gp_num_cus() {   // compute units of the current device (cached: 256 on MI355X)
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+        return cu;
+    }();
+    return n;
+}
+
+static bool wreg_enabled() {
+    static const bool on = [] { const char* e = getenv("GP_GEMM_WREG"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 static long pp_min_tiles() {
@@ -1040,6 +1289,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     const double bytes = xbytes + (double)d->N * d->K * esz + (double)d->M * d->N * (d->out_f32 ? 4 : esz) +
                          (d->epilogue >= GP_EPI_SCALE_RES ? (double)d->M * d->N * esz : 0.0);
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
+    // K = 512 with the weights resident in registers (variant 16)
+    const bool wreg_ok = d->dtype == GP_F16 && d->KH == 0 && d->K == 512 && d->N % 256 == 0 && d->M % 32 == 0 && !d->out_f32 &&
+                         p.splitk == 1 && !d->gn_partial && d->epilogue <= GP_EPI_LRELU && d->ldc % 4 == 0 &&
+                         ((size_t)d->C & 7) == 0 && ((size_t)d->X & 15) == 0 && ((size_t)d->W & 15) == 0 &&
+                         (!d->bias || ((size_t)d->bias & 15) == 0);
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
@@ -1054,7 +1308,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // co_scheduled (several batches in flight: PoseNet(inflight > 1)): a launch need not fill the chip by itself,
             // the 256x256 ping-pong tile is then the cheapest per FLOP even for 32-128 tiles (GP_GEMM_PP_MIN_TILES: A/B)
             const bool fills = tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU;
-            if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            // K = 512, >= 12288 rows, >= 1024 columns (stage-2 fc1 at bs 64): weights in registers (48.5 us against 51.4 for
+            // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py); shorter M does not amortise the
+            // 256 KB weight prologue per CU.  GP_GEMM_WREG=0: A/B switch
+            if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
+            else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
         else variant = 4;
@@ -1066,9 +1324,30 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         !d->out_f32 && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
-    GP_REQUIRE(variant >= 2 && variant <= 13 && variant != 6 && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
+    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "");
+    if (variant == 16) {
+        GP_REQUIRE(wreg_ok, "gp_gemm: variant 16 needs a plain fp16 GEMM with K = 512, N %% 256 == 0, M %% 32 == 0, epilogue none/gelu/relu/lrelu");
+        const int nsl = d->N / 256, tiles = d->M / 32;
+        const int want = gp_num_cus() / nsl > 0 ? gp_num_cus() / nsl : 1;       // M groups so that one workgroup per CU covers the launch
+        p.tiles_m = cdiv(tiles, want);                                            // tiles of 32 rows per group
+        const int groups = cdiv(tiles, p.tiles_m);
+        const int grid = cdiv(groups * nsl, 8) * 8;                               // padded items leave at once (T <= 0)
+        switch (d->epilogue) {
+            case GP_EPI_GELU:
+#ifdef GP_WREG_STAMPS   // investigation build (GP_EXTRA_HIPCC_FLAGS=-DGP_WREG_STAMPS): variant 1616 = the same kernel with s_memtime
+                        // stamps of workgroup 0 into the workspace (scripts/wreg_stamps.py); spills 7 registers -> never in the product
+                if (p.dbg == 16 && p.ws) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_GELU, 16>), dim3(grid), dim3(512), 0, s, p); break; }
+#endif
+                hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_GELU>, dim3(grid), dim3(512), 0, s, p);
+                break;
+            case GP_EPI_RELU: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_RELU>, dim3(grid), dim3(512), 0, s, p); break;
+            case GP_EPI_LRELU: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_LRELU>, dim3(grid), dim3(512), 0, s, p); break;
+            default: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_NONE>, dim3(grid), dim3(512), 0, s, p); break;
+        }
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     if (variant == 13) {
         GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
         p.tiles_m = d->M / 256;

@@ -94,7 +94,7 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None):
+         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, _stamps=None):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
     dt = x.dtype
@@ -129,6 +129,8 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     d.residual = residual.data_ptr() if residual is not None else None
     if splitk > 1:
         d.workspace = _workspace(x.device, splitk * M * N).data_ptr()
+    elif _stamps is not None:      # in-kernel time stamps of variant 1616 (scripts/wreg_stamps.py)
+        d.workspace = _stamps.data_ptr()
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant

@@ -3,7 +3,7 @@
 Stream A loops an AGGRESSOR launch, stream B loops a VICTIM launch into rotating output buffers; after every round the
 victim outputs are compared bitwise with a reference computed alone.  Nothing is shared between the two streams.
 
-  AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | mlp | torchmm | none
+  AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | v16 | mlp | torchmm | none
   VIC = k3 | gnapply | gn | torchfma            (the scalar-FMA victim of r02_race6.log was a build switch of the investigation;
                                                  scripts/repro/pkfma_beside_mfma.hip -DNOPK is its stand-alone form)
 The v1* aggressors are the round-1 register-staged `gemm_kernel`, which no longer exists in the library: run them
@@ -36,6 +36,9 @@ bout = torch.empty(4096, 256, dtype=torch.float16, device=dev)
 if AGG in ("v10", "v8", "v7big", "v4"):
     cx, cw, cb = rnd(4096, 1024).half().to(dev), (rnd(1024, 1024) * 0.03).half().to(dev), rnd(1024).to(dev)
     cout = torch.empty(4096, 1024, dtype=torch.float16, device=dev)
+if AGG == "v16":     # weights-in-registers GEMM (K = 512): stage-2 fc1 shape
+    ex, ew, eb = rnd(16384, 512).half().to(dev), (rnd(2048, 512) * 0.04).half().to(dev), rnd(2048).to(dev)
+    eout = torch.empty(16384, 2048, dtype=torch.float16, device=dev)
 if AGG == "v13":
     dx, dw = rnd(8, 32, 32, 256).half().to(dev), (rnd(256, 2304) * 0.02).half().to(dev)
     dout = torch.empty(8, 32, 32, 256, dtype=torch.float16, device=dev)
@@ -57,6 +60,8 @@ def aggressor():
         ops.gemm(ax, aw, aout, bias=ab, epilogue=EPI_LRELU, variant=1 + 100 * int(AGG[5:]), splitk=1)
     elif AGG in ("v10", "v8", "v7big", "v4"):      # large-tile kernels on a trunk-like shape
         ops.gemm(cx, cw, cout, bias=cb, epilogue=EPI_LRELU, variant={"v10": 10, "v8": 8, "v7big": 7, "v4": 4}[AGG], splitk=1)
+    elif AGG == "v16":
+        ops.gemm(ex, ew, eout, bias=eb, epilogue=1, variant=16, splitk=1)
     elif AGG == "v13":
         ops.conv2d_nhwc(dx, dw, 3, 3, 1, 1, out=dout, variant=13)
     elif AGG == "mlp":

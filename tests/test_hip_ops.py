@@ -155,6 +155,37 @@ def test_gemm_pingpong_bitwise_vs_plain_schedule(variant):
         assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant), ref)
 
 
+def test_gemm_weights_in_registers_variant():
+    """Variant 16 (K = 512, a 256-row slice of W resident in registers, X streamed in 32-row tiles, GELU in the MFMA
+    shadow, counted vmcnt over DMA + stores): bit-identical to the tile kernels where those run their lean epilogue (same
+    k order per accumulator, same GELU roundings), over repeated launches; fp32 formula on the ragged cases (1, 3, 5
+    tiles per row group, groups of unequal length, padded grid items, ldc > N, no bias); refusals."""
+    o = ops()
+    dt, K = torch.float16, 512
+    for (M, N, epi) in [(16384, 2048, o.EPI_GELU), (8192, 512, o.EPI_GELU), (4096, 256, o.EPI_NONE), (2048, 1024, o.EPI_LRELU), (1024, 256, o.EPI_RELU)]:
+        x, w, b = rnd(M, K, seed=91).to("cuda", dt), rnd(N, K, seed=92, scale=K ** -0.5).to("cuda", dt), rnd(N, seed=93).cuda()
+        ref = torch.empty(M, N, dtype=dt, device="cuda")
+        o.gemm(x, w, ref, bias=b, epilogue=epi, variant=8, splitk=1)
+        for _ in range(4):
+            out = torch.full((M, N), 7.0, dtype=dt, device="cuda")
+            o.gemm(x, w, out, bias=b, epilogue=epi, variant=16, splitk=1)
+            assert torch.equal(out, ref), (M, N, epi)
+    for (M, N, epi, bias) in [(32, 256, o.EPI_GELU, True), (96, 256, o.EPI_NONE, False), (160, 512, o.EPI_GELU, True),
+                              (4096 + 32, 768, o.EPI_LRELU, True), (33 * 32, 256, o.EPI_RELU, True)]:
+        x, w = q(rnd(M, K, seed=94), dt), q(rnd(N, K, seed=95, scale=K ** -0.5), dt)
+        b = rnd(N, seed=96) if bias else None
+        lin = x @ w.t() + (b if bias else 0.0)
+        ref = {o.EPI_NONE: lin, o.EPI_GELU: F.gelu(lin), o.EPI_RELU: F.relu(lin), o.EPI_LRELU: F.leaky_relu(lin, 0.1)}[epi]
+        out = torch.zeros(M, N + 8, dtype=dt, device="cuda")
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda() if bias else None, epilogue=epi, variant=16, ldc=N + 8, splitk=1)
+        assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, epi)
+        assert float(out[:, N:].abs().max()) == 0.0
+    x, w = rnd(64, 512, seed=97).to("cuda", dt), rnd(256, 512, seed=98).to("cuda", dt)
+    for bad in (dict(x=x[:48], w=w), dict(x=x, w=w[:192]), dict(x=rnd(64, 256, seed=97).to("cuda", dt), w=rnd(256, 256, seed=98).to("cuda", dt))):
+        with pytest.raises(RuntimeError, match="variant 16"):
+            o.gemm(bad["x"], bad["w"], torch.empty(bad["x"].shape[0], bad["w"].shape[0], dtype=dt, device="cuda"), variant=16, splitk=1)
+
+
 @pytest.mark.parametrize("C", [128, 256])
 def test_convnext_mlp_fused(C):
     """Fused fc1 -> GELU -> fc2 -> gamma * . + shortcut against the fp32 formula (hidden rounded to fp16 like the
