@@ -88,6 +88,15 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 // instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the fc1 epilogues and the
 // GroupNorm+GELU passes VALU bound.  The fp32 storage path keeps gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Workgroup id -> work item so that each XCD (workgroup ids equal mod 8 share one, round-robin placement) owns ONE contiguous
+// run of the n items: XCD x of 8 gets items [x n/8, (x+1) n/8) (bijective for any n).  Every kernel of the ConvNeXt block
+// chain (depth-wise conv, fused MLP, fc1, fc2) uses this order over the rows of the activation matrix, so the rows an XCD
+// writes are the rows its workgroups read in the next launch (they are still in its private L2).  Speed only.
+__device__ __forceinline__ int xcd_chunk(int bid, int n) {
+    const int q = n >> 3, r8 = n & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+}
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N) (bodies that need constexpr indices)
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {

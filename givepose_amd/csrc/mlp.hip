@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const long m0 = (long)blockIdx.x * 256 + wave * 32;
+    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + wave * 32;   // an XCD's workgroups = a contiguous run of rows (common.hpp)
 
     // ---- bias of the hidden layer -> LDS (read back per chunk as the accumulators' initial value)
     float* b1s = reinterpret_cast<float*>(smem + RING);

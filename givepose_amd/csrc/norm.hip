@@ -345,7 +345,8 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tpr = W / TW, tpi = tpr * (H / TH);
-    const int b = blockIdx.x / tpi, tin = blockIdx.x - b * tpi;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);   // tiles of an XCD = a contiguous run of rows (common.hpp)
+    const int b = bid / tpi, tin = bid - b * tpi;
     const int h0 = (tin / tpr) * TH, w0 = (tin % tpr) * TW;
     const half_t* xb = x + (long)b * H * W * C;
     const half_t* zero = reinterpret_cast<const half_t*>(gp_zero_page_tu);
