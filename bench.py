@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--kernels-out", default=None, help="write the per-label launch table of the roofline pass (all labels) to this JSON file")
     args = ap.parse_args()
 
     try:        # before anything touches the GPU (the .git directory does not travel to the GPU box: usually absent there)
@@ -245,12 +246,15 @@ def main():
                 line["roofline_gather"]["traffic"] = round(t["dcnv3"]["hbm_bytes_per_step"] / classes["dcnv3"]["launches_per_step"])
         line["kernel_classes"] = classes
         line["kernels_top8"] = top[:8]
+        if args.kernels_out:
+            with open(args.kernels_out, "w") as f:
+                json.dump(top, f, indent=1)
         line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
 
     if rank == 0:
         note("roofline leg done")
     # ---------------- parity mode: fp32 storage, the mode that meets 1e-4 (rank 0; serial; a few steps)
-    if rank == 0 and not args.no_parity and args.dtype == "f16":
+    if rank == 0 and world == 1 and not args.no_parity and args.dtype == "f16":      # N = 1 only: the other ranks of an N > 1 run wait in the final barrier
         netp = PoseNet(cfg, dtype=torch.float32, seed=0, use_graph=not args.no_graph, inflight=1).to(dev)
         stp = netp.static_inputs(B, dev)
         for k, v in host.items():
@@ -279,7 +283,7 @@ def main():
         note("parity leg done")
     # ---------------- H->D inclusive rate (never `value`): the boundary hands over host tensors, so time
     # the same step with every input copied from pinned host memory first, copy and step serialised (no overlap)
-    if rank == 0 and not args.no_roofline and not args.no_h2d:
+    if rank == 0 and world == 1 and not args.no_roofline and not args.no_h2d:
         static = serial.static_inputs(B, dev)
         pinned = {k: torch.from_numpy(v).reshape(static[k].shape).to(static[k].dtype).pin_memory() for k, v in host.items()}
         def step_h2d():

@@ -971,7 +971,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 // the issue port 8 of their 16 cycles (1 024) and the GELU of 2 x 16 x 64 elements is 472 four-cycle instructions
 // (1 888): the MFMA + GELU block takes 3 400-3 600 of the period's ~4 100 cycles (the rest: stores, vmcnt wait,
 // barrier), so the matrix pipe cannot be more than ~58 % busy while the GELU shares the SIMD.  Measured (interleaved
-// medians, scripts/wreg_ab.py): 48.3 us against 47.5 (ping-pong tile) and 53.4 (256 x 128 tile) alone; end to end the
+// medians, scripts/gemm_ab.py): 48.3 us against 47.5 (ping-pong tile) and 53.4 (256 x 128 tile) alone; end to end the
 // step gains 4 % serial and 0.7 % with three batches in flight, because a workgroup's H rows stay in the L2 of the XCD
 // that the following fc2 launch reads them from (fc2 49.6 -> 45.3 us).
 // Hazards: buffer (q+3)&3 was last read in period q-1, which every wave left through the barrier that opens period q
