@@ -162,7 +162,9 @@ def test_gemm_weights_in_registers_variant():
     tiles per row group, groups of unequal length, padded grid items, ldc > N, no bias); refusals."""
     o = ops()
     dt, K = torch.float16, 512
-    for (M, N, epi) in [(16384, 2048, o.EPI_GELU), (8192, 512, o.EPI_GELU), (4096, 256, o.EPI_NONE), (2048, 1024, o.EPI_LRELU), (1024, 256, o.EPI_RELU)]:
+    # tiles per row group T = 16, 2, 1, 1, 1, then 3 / 5 / 7 (prologue, steady state and drain of the counted vmcnt window)
+    for (M, N, epi) in [(16384, 2048, o.EPI_GELU), (8192, 512, o.EPI_GELU), (4096, 256, o.EPI_NONE), (2048, 1024, o.EPI_LRELU), (1024, 256, o.EPI_RELU),
+                        (24576, 256, o.EPI_GELU), (40960, 256, o.EPI_GELU), (57344, 256, o.EPI_NONE)]:
         x, w, b = rnd(M, K, seed=91).to("cuda", dt), rnd(N, K, seed=92, scale=K ** -0.5).to("cuda", dt), rnd(N, seed=93).cuda()
         ref = torch.empty(M, N, dtype=dt, device="cuda")
         o.gemm(x, w, ref, bias=b, epilogue=epi, variant=8, splitk=1)
