@@ -27,7 +27,7 @@ class GemmDesc(Structure):
                 ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
                 ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int),
                 ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
-                ("co_scheduled", c_int)]
+                ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)

@@ -38,6 +38,8 @@ struct GemmKP {
     int ln_nsl;
     float ln_eps;
     int dbg;  // timing-only ablations of the large-tile kernel: 1 = no in-loop DMA, 2 = no MFMA/LDS reads (wrong results)
+    const char* pf;   // gp_gemm_desc.prefetch: bytes [0, pf_bytes) touched by the workgroups as they start (hint)
+    long pf_bytes;
 };
 
 template <typename T>
@@ -292,6 +294,36 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
 
 typedef __attribute__((address_space(3))) char lds_char_t;
 
+// gp_gemm_desc.prefetch: the launch's workgroups touch [pf, pf + pf_bytes) once, 1 KB per wave instruction (16 B per lane),
+// at most NPF instructions per wave.  The loads have register destinations that nothing reads -- but a load's registers are
+// written when it LANDS, so they must stay reserved until then: prefetch_issue() returns them, prefetch_retire() is
+// placed behind the kernel's first vmcnt wait (vmcnt retires in issue order and these loads are older than everything the
+// kernel counts, so that wait covers them) and "uses" them there, which keeps hipcc from handing them out earlier.
+constexpr int NPF = 4;
+typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: no 'v' constraint)
+struct PfSink { pf_u32x4 r0, r1, r2, r3; };
+__device__ __forceinline__ void prefetch_one(const GemmKP& p, long i, long hi, int lane, pf_u32x4& r) {
+    const long off = (i << 10) + lane * 16;
+    r = pf_u32x4{0u, 0u, 0u, 0u};
+    if (i < hi && off + 16 <= p.pf_bytes) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(p.pf + off) : "memory");
+}
+__device__ __forceinline__ PfSink prefetch_issue(const GemmKP& p, int bid, int nwg, int wave, int nwaves, int lane) {
+    PfSink s;
+    s.r0 = s.r1 = s.r2 = s.r3 = pf_u32x4{0u, 0u, 0u, 0u};
+    if (p.pf) {
+        const long pieces = (p.pf_bytes + 1023) >> 10, per = (pieces + nwg - 1) / nwg;
+        const long lo = (long)bid * per, hi = min(pieces, lo + per);
+        prefetch_one(p, lo + wave, hi, lane, s.r0);
+        prefetch_one(p, lo + wave + nwaves, hi, lane, s.r1);
+        prefetch_one(p, lo + wave + 2 * nwaves, hi, lane, s.r2);
+        prefetch_one(p, lo + wave + 3 * nwaves, hi, lane, s.r3);
+    }
+    return s;
+}
+__device__ __forceinline__ void prefetch_retire(const PfSink s) {
+    asm volatile("" ::"v"(s.r0), "v"(s.r1), "v"(s.r2), "v"(s.r3));
+}
+
 // One LDS-DMA wave instruction: 64 lanes x 16 B from per-lane global addresses to LDS [lds_addr, +1 KB).
 // Issued from inline asm so that hipcc does not count it: with the builtin form hipcc puts an
 // s_waitcnt vmcnt(0) in front of the first ds_read after it (it cannot tell the DMA's LDS destination from the
@@ -353,6 +385,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const PfSink pfs = prefetch_issue(p, bid + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, wave, WM * WN, lane);   // gp_gemm_desc.prefetch (hint)
 
     const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
     const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
@@ -546,6 +579,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             if (p.nkt >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        prefetch_retire(pfs);
         __builtin_amdgcn_s_barrier();
         if (grp) __builtin_amdgcn_s_barrier();
         int buf = 0, nbuf = LEAD;
@@ -608,6 +642,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         };
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        prefetch_retire(pfs);
         __syncthreads();
         rd(0, co0, xf0, wf0);
         if (p.nkt > 1) stage(1, 1);
@@ -635,6 +670,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         if (i < p.nkt) stage(i, i);
     if (p.nkt > NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    prefetch_retire(pfs);
     __syncthreads();
     int buf = 0, nbuf = NS - 1;
     for (int kt = 0; kt < p.nkt; ++kt) {
@@ -828,6 +864,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     unsigned xoff[4];
     unsigned xvalid = 0;
     const char* ximg = reinterpret_cast<const char*>(X + (long)img * p.H * WIMG * Cin);
+    const PfSink pfs = prefetch_issue(p, blockIdx.x, gridDim.x, wave, 8, lane);   // gp_gemm_desc.prefetch (hint)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = wave + 8 * j, px = i * 16 + lrow;
@@ -888,6 +925,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 #pragma unroll
     for (int i = 0; i < LEAD; ++i) stage_w(i, 0, i);
     wait_vmcnt(2 * (LEAD - 1));
+    prefetch_retire(pfs);
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();
 
@@ -1118,6 +1156,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (t < T) dma(t);
+    const PfSink pfs = prefetch_issue(p, bid, gridDim.x, wave, 8, lane);
     // ---- W fragments: lane (fr, fq) of fragment (nt, ks) holds W[nb + nt*16 + fr][ks*32 + fq*8 .. +8]
     const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + fr) * K + fq * 8;
 #pragma unroll
@@ -1131,6 +1170,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     // everything in flight so far (three X tiles, W, bias) has landed before the loop starts.  The builtin, not inline
     // asm: hipcc tracks it, and would otherwise wait for the W loads inside the loop (vmcnt(0) in every period)
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    prefetch_retire(pfs);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1220,6 +1260,11 @@ static int gp_num_cus() {   // compute units of the current device (cached: 256 
     return n;
 }
 
+static bool prefetch_enabled() {   // GP_GEMM_PREFETCH=0: A/B switch for gp_gemm_desc.prefetch
+    static const bool on = [] { const char* e = getenv("GP_GEMM_PREFETCH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool wreg_enabled() {
     static const bool on = [] { const char* e = getenv("GP_GEMM_WREG"); return !(e && e[0] == '0'); }();
     return on;
@@ -1260,6 +1305,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     p.M = d->M; p.N = d->N; p.K = d->K; p.ldx = d->ldx; p.ldc = d->ldc; p.ldres = d->ldres;
     p.epi = d->epilogue; p.out_f32 = d->out_f32;
     p.ln_stats = d->ln_stats; p.ln_s = d->ln_colsum; p.ln_nsl = d->ln_nslab; p.ln_eps = d->ln_eps;
+    if (d->prefetch && d->prefetch_bytes > 0 && prefetch_enabled()) { p.pf = reinterpret_cast<const char*>(d->prefetch); p.pf_bytes = d->prefetch_bytes; }
     if (d->gn_partial) {
         GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
                    "gp_gemm: fused GroupNorm needs 4 or 8 channels per group");

@@ -94,9 +94,10 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, _stamps=None):
+         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, prefetch=None, _stamps=None):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
-    dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM."""
+    dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM.
+    prefetch = a tensor (the weights of the NEXT launch on this stream) to be pulled towards the caches meanwhile: a hint."""
     dt = x.dtype
     code = dtype_code(dt)
     _chk(x, "x"), _chk(w, "w", dt), _chk(out, "out")
@@ -135,6 +136,8 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
     d.co_scheduled = 1 if CO_SCHEDULED else 0
+    if prefetch is not None:
+        d.prefetch, d.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     if ln is not None:       # (row moments (M,2,nslab), column sums of w, nslab, eps): EPI_LNFOLD_GELU
         d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2], ln[3]
     if gn is not None:       # (partial buffer, groups, pixels per image): fused GroupNorm statistics of the output
@@ -144,7 +147,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
 
 
 def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None,
-                residual=None):
+                residual=None, prefetch=None):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -153,7 +156,7 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
         out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
          residual=None if residual is None else residual.view(B * Ho * Wo, -1),
-         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn)
+         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn, prefetch=prefetch)
     return out
 
 

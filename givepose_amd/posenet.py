@@ -302,7 +302,7 @@ class PoseNet(nn.Module):
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
         """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows."""
-        ops.gemm(feat2d, W[head + ".deconv_w"], buf["cols"])
+        ops.gemm(feat2d, W[head + ".deconv_w"], buf["cols"], prefetch=W[f"{head}.c3_w"])
         y = ops.deconv_col2im(buf["cols"], buf["ya16"], B, 8, 8, 256)
         self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
         cur, r = y, 16
@@ -311,7 +311,9 @@ class PoseNet(nn.Module):
                 r *= 2
                 cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"])
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
-            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r))
+            nxt = {3: 4, 4: 6, 6: 7, 7: 9, 9: 10}.get(i)
+            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r),
+                            prefetch=W[f"{head}.c{nxt}_w"] if nxt else None)
             if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
                 ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
                                         W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"])
@@ -376,9 +378,12 @@ class PoseNet(nn.Module):
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
                                      W[q + "gamma"], x2d, x2d)
                     continue
-                ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU)
+                # every GEMM-class launch may pull the weights of a later one towards the caches while it runs
+                # (gp_gemm_desc.prefetch: a hint; the 128x128-tile GEMMs run 10-25 % longer on weights that come from HBM)
+                ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU, prefetch=W[q + "fc2_w"])
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
-                         gamma=W[q + "gamma"], residual=x2d)
+                         gamma=W[q + "gamma"], residual=x2d,
+                         prefetch=W.get(f"ds{s + 1}.w") if b == n - 1 else None)
         if cfg.main_backbone == "convnext":
             feat = x                                # (B,8,8,1024)
         fc = dims[-1]
@@ -465,11 +470,12 @@ class PoseNet(nn.Module):
         self._gn(p, W["pnp.g0_w"], W["pnp.g0_b"], ACT_RELU, buf)
         for li in (1, 2):
             hw = nxt_hw = (32 >> li) ** 2
-            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"], gn=self._gnarg(buf, hw))
+            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"], gn=self._gnarg(buf, hw),
+                                  prefetch=W["pnp.c2_w"] if li == 1 else W["pnp.fc1_w"])     # (fc1: the first 4 of its 33 MB)
             self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf, fused=True)
             p = nxt
-        ops.gemm(p.view(B, 8192), W["pnp.fc1_w"], buf["fc1"], bias=W["pnp.fc1_b"], epilogue=EPI_LRELU)
-        ops.gemm(buf["fc1"], W["pnp.fc2_w"], buf["hh"], bias=W["pnp.fc2_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048)
+        ops.gemm(p.view(B, 8192), W["pnp.fc1_w"], buf["fc1"], bias=W["pnp.fc1_b"], epilogue=EPI_LRELU, prefetch=W["pnp.fc2_w"])
+        ops.gemm(buf["fc1"], W["pnp.fc2_w"], buf["hh"], bias=W["pnp.fc2_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048, prefetch=W["pnp.fc2z_w"])
         ops.gemm(buf["fc1"][:, 1024:], W["pnp.fc2z_w"], buf["hz"], bias=W["pnp.fc2z_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048)
         ops.pose_tail(buf["hh"], buf["hz"], 256, W, buf["cam_K"], buf["bbox_center"], buf["resize_ratio"], buf["roi_wh"],
                       cfg.dataset == "wild6d", cfg.t_type == "site", buf, B)

@@ -132,6 +132,13 @@ typedef struct gp_gemm_desc {
     /* != 0: the caller keeps other launches running beside this one (independent batches in flight), so the tile is
      * chosen for cost per FLOP rather than for filling 256 CUs alone (variant == 0 only) */
     int co_scheduled;
+    /* optional hint: `prefetch_bytes` bytes at `prefetch` (the weights of the launch that FOLLOWS on this stream) are
+     * touched by this launch's workgroups as they start, so that they are in L2 / Infinity Cache when the next kernel
+     * wants them (the ~230 MB of weights of a step do not survive a step in the caches; a 128x128-tile GEMM whose
+     * weights arrive from HBM runs 10-25 % longer).  Speed only, never dereferenced for a result.  NULL / 0 = off.
+     * Honoured by every variant. */
+    const void* prefetch;
+    long prefetch_bytes;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 

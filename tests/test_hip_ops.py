@@ -188,6 +188,31 @@ def test_gemm_weights_in_registers_variant():
             o.gemm(bad["x"], bad["w"], torch.empty(bad["x"].shape[0], bad["w"].shape[0], dtype=dt, device="cuda"), variant=16, splitk=1)
 
 
+def test_gemm_prefetch_hint_changes_nothing():
+    """gp_gemm_desc.prefetch is a hint: the workgroups touch the given bytes (any length, 16-byte pieces, at most four
+    1-KB pieces per wave) and the result is bitwise the one without it -- every schedule family, conv and window conv."""
+    o = ops()
+    dt = torch.float16
+    pf_big = torch.zeros(33 * 1024 * 1024 // 2 + 5, dtype=dt, device="cuda")     # 33 MB + 10 bytes
+    for pf in (pf_big, pf_big[:500], pf_big[:8], pf_big[:2048 + 4], pf_big[: 2 * 1024 * 1024]):
+        for (M, N, K, variant) in [(4096, 1024, 512, 7), (4096, 1024, 512, 10), (16384, 2048, 512, 16), (2048, 512, 256, 8),
+                                   (1024, 512, 1024, 4), (1000, 260, 128, 5)]:
+            x, w, b = rnd(M, K, seed=101).to("cuda", dt), rnd(N, K, seed=102, scale=K ** -0.5).to("cuda", dt), rnd(N, seed=103).cuda()
+            ref = torch.empty(M, N, dtype=dt, device="cuda")
+            out = torch.empty(M, N, dtype=dt, device="cuda")
+            o.gemm(x, w, ref, bias=b, epilogue=o.EPI_GELU, variant=variant, splitk=1)
+            o.gemm(x, w, out, bias=b, epilogue=o.EPI_GELU, variant=variant, splitk=1, prefetch=pf)
+            assert torch.equal(out, ref), (M, N, K, variant, pf.numel())
+        xc, wc = rnd(8, 32, 32, 256, seed=104).to("cuda", dt), rnd(256, 9 * 256, seed=105, scale=0.02).to("cuda", dt)
+        for variant in (13, 7):
+            assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant, prefetch=pf), o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant))
+    xs, ws = rnd(64, 8192, seed=106).to("cuda", dt), rnd(2048, 8192, seed=107, scale=0.01).to("cuda", dt)   # split-K path
+    ref, out = torch.empty(64, 2048, dtype=dt, device="cuda"), torch.empty(64, 2048, dtype=dt, device="cuda")
+    o.gemm(xs, ws, ref, variant=4, splitk=8)
+    o.gemm(xs, ws, out, variant=4, splitk=8, prefetch=pf_big)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("C", [128, 256])
 def test_convnext_mlp_fused(C):
     """Fused fc1 -> GELU -> fc2 -> gamma * . + shortcut against the fp32 formula (hidden rounded to fp16 like the
