@@ -106,28 +106,25 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// GELU for fp16 storage: gelu(x) = x * Phi(x), Phi(x) = 0.5 + xc * h(xc^2), xc = clamp(x, +-4.4); 2 h = r, the degree-8
+// minimax fit of erf(x / sqrt 2) / x in x^2 (LP fit, weighted by the GELU error x^2 / 2, constrained to meet erf at the
+// clamp so that no second clamp is needed: beyond it the result is x * (1 - 5.4e-6) resp. x * 5.4e-6).  The halved
+// coefficients are exact (powers of two), so h is bit for bit r / 2.  12 operations per element: clamp, square, 8 FMAs
+// (Horner), Phi = fma(xc, h, 0.5), x * Phi  (until round 2: 13 -- 0.5 x and x/2 * erf + x/2 as separate steps).
+constexpr float GELU_H[9] = {0.5f * 6.9778819482e-11f, 0.5f * -7.3778779375e-09f, 0.5f * 3.4381198132e-07f, 0.5f * -9.3718131897e-06f,
+                             0.5f * 1.6778340171e-04f, 0.5f * -2.1052074914e-03f, 0.5f * 1.9270481587e-02f, 0.5f * -1.3212860816e-01f,
+                             0.5f * 7.9751050727e-01f};
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
-    // erf(x / sqrt 2) = xc * r(xc^2), xc = clamp(x, +-4.4); r: degree-8 minimax (LP fit, weighted by the GELU error
-    // x^2 / 2, constrained to meet erf at the clamp so that no second clamp is needed: beyond it the result is
-    // x * (1 - 5.4e-6) resp. x * 5.4e-6).  7 VALU ops per element: 2 v_med3 + 12 packed ops per pair.
     f32x2 xc;
     xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.4f, 4.4f);
     xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.4f, 4.4f);
     const f32x2 t = xc * xc;
-    f32x2 p = {6.9778819482e-11f, 6.9778819482e-11f};
-    p = __builtin_elementwise_fma(p, t, f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
-    p = __builtin_elementwise_fma(p, t, f32x2{3.4381198132e-07f, 3.4381198132e-07f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-9.3718131897e-06f, -9.3718131897e-06f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.6778340171e-04f, 1.6778340171e-04f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-2.1052074914e-03f, -2.1052074914e-03f});
-    p = __builtin_elementwise_fma(p, t, f32x2{1.9270481587e-02f, 1.9270481587e-02f});
-    p = __builtin_elementwise_fma(p, t, f32x2{-1.3212860816e-01f, -1.3212860816e-01f});
-    p = __builtin_elementwise_fma(p, t, f32x2{7.9751050727e-01f, 7.9751050727e-01f});
-    const f32x2 e = xc * p;
-    const f32x2 hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, e, hx);
+    f32x2 p = __builtin_elementwise_fma(f32x2{GELU_H[0], GELU_H[0]}, t, f32x2{GELU_H[1], GELU_H[1]});
+#pragma unroll
+    for (int k = 2; k < 9; ++k) p = __builtin_elementwise_fma(p, t, f32x2{GELU_H[k], GELU_H[k]});
+    return x * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
 }
-// the same polynomial on eight 2-vectors walked in lock step: eight independent dependency chains, so the packed FMAs
+// the same polynomial on NC 2-vectors walked in lock step: NC independent dependency chains, so the packed FMAs
 // issue back to back instead of waiting out each other's latency (fused MLP kernel, csrc/mlp.hip)
 template <int NC>
 __device__ __forceinline__ void gelu_poly2_xn(f32x2* x) {
@@ -140,22 +137,16 @@ __device__ __forceinline__ void gelu_poly2_xn(f32x2* x) {
 #pragma unroll
     for (int i = 0; i < NC; ++i) t[i] = xc[i] * xc[i];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(f32x2{6.9778819482e-11f, 6.9778819482e-11f}, t[i], f32x2{-7.3778779375e-09f, -7.3778779375e-09f});
-    constexpr float cf[7] = {3.4381198132e-07f, -9.3718131897e-06f, 1.6778340171e-04f, -2.1052074914e-03f,
-                             1.9270481587e-02f, -1.3212860816e-01f, 7.9751050727e-01f};
+    for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(f32x2{GELU_H[0], GELU_H[0]}, t[i], f32x2{GELU_H[1], GELU_H[1]});
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
+    for (int k = 2; k < 9; ++k)
 #pragma unroll
-        for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{cf[k], cf[k]});
+        for (int i = 0; i < NC; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2{GELU_H[k], GELU_H[k]});
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const f32x2 e = xc[i] * p[i];
-        const f32x2 hx = x[i] * 0.5f;
-        x[i] = __builtin_elementwise_fma(hx, e, hx);
-    }
+    for (int i = 0; i < NC; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], p[i], f32x2{0.5f, 0.5f});
 }
 __device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) { gelu_poly2_xn<8>(x); }
-// the same polynomial as 13 separable slices of one operation per element, for callers that hide it in the shadow of
+// the same polynomial as 12 separable slices of one operation per element, for callers that hide it in the shadow of
 // MFMAs a slice at a time (gemm_wreg_kernel): slice S of chain c works on x[c] with the scratch xc[c], t[c], p[c].
 // Plain v_fma_f32 / v_mul_f32 from inline asm, NOT packed: beside MFMAs one v_pk_fma_f32 costs ~22 cycles more than two
 // v_fma_f32 (MI355X_MICROARCH.md, constants table), and hipcc packs whatever it can.  Same roundings as gelu_poly2
@@ -163,19 +154,17 @@ __device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) { gelu_poly2_xn<8>(
 __device__ __forceinline__ float vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float vfma_s(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c)); return d; }
 __device__ __forceinline__ float vmul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+constexpr int GELU_SLICES = 12;
 template <int S>
 __device__ __forceinline__ void gelu_poly2_slice(f32x2& x, f32x2& xc, f32x2& t, f32x2& p, float c1v) {
-    constexpr float cf[7] = {3.4381198132e-07f, -9.3718131897e-06f, 1.6778340171e-04f, -2.1052074914e-03f,
-                             1.9270481587e-02f, -1.3212860816e-01f, 7.9751050727e-01f};
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         if constexpr (S == 0) xc[e] = __builtin_amdgcn_fmed3f(x[e], -4.4f, 4.4f);
         else if constexpr (S == 1) t[e] = vmul(xc[e], xc[e]);
-        else if constexpr (S == 2) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(6.9778819482e-11f), "v"(t[e]), "v"(c1v)); p[e] = d; }   // c1v = -7.3778779375e-09f in a VGPR (one SGPR per VALU instruction)
-        else if constexpr (S >= 3 && S <= 9) p[e] = vfma_s(p[e], t[e], cf[S - 3 < 0 ? 0 : (S - 3 > 6 ? 6 : S - 3)]);
-        else if constexpr (S == 10) xc[e] = vmul(xc[e], p[e]);            // e
-        else if constexpr (S == 11) { float d; asm("v_mul_f32 %0, 0.5, %1" : "=v"(d) : "v"(x[e])); t[e] = d; }   // hx
-        else if constexpr (S == 12) x[e] = vfma(t[e], xc[e], t[e]);
+        else if constexpr (S == 2) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(GELU_H[0]), "v"(t[e]), "v"(c1v)); p[e] = d; }   // c1v = GELU_H[1] in a VGPR (one SGPR per VALU instruction)
+        else if constexpr (S >= 3 && S <= 9) p[e] = vfma_s(p[e], t[e], GELU_H[S - 1 < 2 ? 2 : (S - 1 > 8 ? 8 : S - 1)]);
+        else if constexpr (S == 10) { float d; asm("v_fma_f32 %0, %1, %2, 0.5" : "=v"(d) : "v"(xc[e]), "v"(p[e])); p[e] = d; }   // Phi
+        else if constexpr (S == 11) x[e] = vmul(x[e], p[e]);
     }
 }
 __device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }

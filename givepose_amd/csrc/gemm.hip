@@ -999,7 +999,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 // wave reads the whole tile as B fragments (2 ds_read_b128 per 4 MFMAs).  Per CU: 256 KB + rows x 1 KB (0.77 MB at
 // 512 rows per group) and ONE barrier per 32 rows instead of one per K step.
 // Schedule (one period = one tile, one barrier): every wave runs the 64 MFMAs of tile q with the ACTIVATION of tile
-// q-1 in their shadow -- after each MFMA four plain v_fma_f32 / v_mul_f32 of the GELU polynomial (13 slices of one
+// q-1 in their shadow -- after each MFMA four plain v_fma_f32 / v_mul_f32 of the GELU polynomial (12 slices of one
 // operation per element, two chains per MFMA; inline asm, not packed: beside MFMAs a v_pk_fma_f32 costs ~22 cycles
 // more than two v_fma_f32) -- B fragments read two K steps ahead with counted lgkmcnt, the wave's four LDS-DMA
 // instructions of tile q+3 spread over the K steps (the two waves of a SIMD issue theirs two K steps apart), then the
@@ -1065,10 +1065,10 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     half_t* Cw = reinterpret_cast<half_t*>(p.C) + (m0 + fr) * (long)p.ldc + nb + fq * 4;
     // B fragments of a tile are read two K steps ahead of their MFMAs into a ring of three register pairs; SHADOW: the
     // GELU of the previous tile (v) is issued in the shadow of the MFMAs, two packed VALU operations behind each MFMA
-    // (13 slices x 4 chains per half tile: K steps 0-7 carry chains 0-3, K steps 8-15 chains 4-7).  sched_barriers pin
+    // (12 slices x 4 chains per half tile: K steps 0-7 carry chains 0-3, K steps 8-15 chains 4-7).  sched_barriers pin
     // the order: hipcc otherwise clusters the VALU work and waits lgkmcnt(0) in front of every MFMA pair.
     f32x2 gx[4], gt[4], gp[4];
-    float c1v = -7.3778779375e-09f;
+    float c1v = GELU_H[1];
     asm volatile("" : "+v"(c1v));   // a VGPR constant
     auto mfmas = [&](int t, auto shadow, int tdma) {   // tdma: tile whose four DMA instructions ride along (< 0: none)
         constexpr bool SH = decltype(shadow)::value && EPI == GP_EPI_GELU && !(ABL & 8);
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
                 if constexpr (SH) {
                     constexpr int half = ks / 8, slot = (ks % 8) * 2 + j / 2;      // slice index of this K step: two per K step
                     constexpr int c0 = (j % 2) * 2;                                 // chains c0, c0 + 1
-                    if constexpr (slot < 13) {
+                    if constexpr (slot < GELU_SLICES) {
                         gelu_poly2_slice<slot>(v[half * 4 + c0], gx[c0], gt[c0], gp[c0], c1v);
                         gelu_poly2_slice<slot>(v[half * 4 + c0 + 1], gx[c0 + 1], gt[c0 + 1], gp[c0 + 1], c1v);
                     }

@@ -175,9 +175,13 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
         if (p.dbg == 1) {
         } else if constexpr (C == 128) {
             gelu_poly2_x8(v);
-        } else {   // C = 256 has no registers left for eight chains in flight
+        } else {   // C = 256 has no registers left for eight chains in flight: two at a time, each pair made to wait for
+                   // the one before it (an empty asm that "writes" the next pair after "reading" the finished one)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = gelu_poly2(v[i]);
+            for (int i = 0; i < 8; i += 2) {
+                gelu_poly2_xn<2>(v + i);
+                if (i + 2 < 8) asm volatile("" : "+v"(v[i + 2]), "+v"(v[i + 3]) : "v"(v[i]), "v"(v[i + 1]));
+            }
         }
         uint4 hb[MT];
 #pragma unroll
