@@ -157,16 +157,36 @@ __global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
 // One wavefront per output pixel; G == 4, D == 64 (lane = g*16 + cv), P <= 16.
 // KS > 0: kernel size known at compile time and remove_center == 0 (the PoseNet geometry is KS = 3): the tap loops
 // unroll and the (tap index -> i, j) bookkeeping disappears; the arithmetic per tap is the same expression.
-template <typename T, typename OT, int KS = 0>
+// PATCH (KS == 3, Ho % 4 == 0, Wo % 4 == 0): a workgroup is a 4 x 4 patch of output pixels of ONE group (blockIdx.y): wave =
+// patch row, 16-lane row = pixel, lane = 4 of the group's 64 channels.  The taps of neighbouring output pixels land on
+// overlapping input pixels, and one group's share of an input pixel is a single 128-byte line, so the patch's footprint
+// (about 10 x 10 input pixels = 13 KB) stays in the CU's 32-KB L1: the wave-per-pixel mapping below pulls every one of its
+// 36 x 512 gathered bytes from L2 (1.2 GB per launch at 64 x 64 = 4.7 MB per CU, i.e. the ~55 GB/s a CU gets from L2).
+template <typename T, typename OT, int KS = 0, bool PATCH = false>
 __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
+    static_assert(!PATCH || KS == 3, "patch mapping: 3 x 3 only");
     const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= p.rows) return;  // whole wave exits together
-    const int g = lane >> 4, t = lane & 15;
-    const int wo = (int)(r % p.Wo);
-    const long t2 = r / p.Wo;
-    const int ho = (int)(t2 % p.Ho);
-    const int b = (int)(t2 / p.Ho);
+    long r;
+    int g, wo, ho, b;
+    const int t = lane & 15;
+    if constexpr (PATCH) {
+        const int ppr = p.Wo >> 2, ppi = ppr * (p.Ho >> 2);
+        const int pid = blockIdx.x;
+        b = pid / ppi;
+        const int pin = pid - b * ppi;
+        ho = (pin / ppr) * 4 + (threadIdx.x >> 6);
+        wo = (pin % ppr) * 4 + (lane >> 4);
+        g = blockIdx.y;
+        r = ((long)b * p.Ho + ho) * p.Wo + wo;
+    } else {
+        r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (r >= p.rows) return;  // whole wave exits together
+        g = lane >> 4;
+        wo = (int)(r % p.Wo);
+        const long t2 = r / p.Wo;
+        ho = (int)(t2 % p.Ho);
+        b = (int)(t2 / p.Ho);
+    }
     const int K = KS > 0 ? KS : p.K, rc = KS > 0 ? 0 : p.rc;
     const int P = K * K - rc;
     // lane t < P of row g owns tap t
@@ -186,7 +206,8 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     const int halfk = (p.dil * (K - 1)) >> 1;
     const float p0_w_ = (float)(halfk - p.pad + wo * p.stride) - halfk * p.os;
     const float p0_h_ = (float)(halfk - p.pad + ho * p.stride) - halfk * p.os;
-    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * 256 + lane * 4;
+    const int cl = g * 16 + t;   // this lane's channel quad (== lane in the wave-per-pixel mapping)
+    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * 256 + cl * 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (KS > 0) {
         // Lane t < 9 of every 16-lane row owns tap t of its group and works out ONCE what all 16 lanes of the row need
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
             dx = (unsigned)((x1 - x0) * 256) * (unsigned)sizeof(T);
             dy = (unsigned)((y1 - y0) * p.W * 256) * (unsigned)sizeof(T);
         }
-        const unsigned lo = (unsigned)lane * 4u * (unsigned)sizeof(T);
+        const unsigned lo = (unsigned)cl * 4u * (unsigned)sizeof(T);
 #define GP_RSF(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
 #define GP_RSU(v, q) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (q), 0xF, 0xF, false)
 #define GP_TAP(q)                                                                                              \
@@ -259,11 +280,18 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
                 ++q;
             }
     }
-    st4(reinterpret_cast<T*>(p.out) + r * 256 + lane * 4, acc);
+    st4(reinterpret_cast<T*>(p.out) + r * 256 + cl * 4, acc);
+}
+
+static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
+    static const bool on = [] { const char* e = getenv("GP_DCN_PATCH"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
-    if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
+    if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled()) {
+        hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
+    } else if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
     } else if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
