@@ -122,7 +122,10 @@ typedef struct gp_gemm_desc {
      * M = B*gn_hw; consumed by gp_groupnorm_apply(..., chunks = gn_hw/64). NULL = off. */
     float* gn_partial;
     int gn_groups, gn_hw;
-    int variant; /* 0 = choose by shape; 1 = 128x128 tile (split-K capable), 2 = 256x128, 3 = 256x256 LDS-DMA tiles */
+    int variant; /* 0 = choose by shape (the product path); otherwise one schedule, for tests and A/B runs: 4 = 128x128 LDS-DMA
+                  * tile (the split-K carrier), 5 / 9 = its 4-stage forms, 7 = 128x128 software-pipelined, two workgroups per
+                  * CU, 2 / 8 = 256x128, 3 = 256x256, 10 / 11 / 12 = ping-pong 256x256 / 128x256 / 5-stage, 13 = 3x3 window
+                  * conv (Cout 256), 16 = K 512 with the weight slice resident in registers.  + 100 n: timing ablations. */
     /* GP_EPI_LNFOLD_GELU only: ln_stats (M, 2, ln_nslab) fp32 partial (sum, sum of squares) of each X row over
      * ln_nslab channel slabs; ln_colsum (N) fp32; ln_eps.  Requires M % 256 == 0, N % 256 == 0, fp16 output. */
     const float* ln_stats;
