@@ -61,6 +61,138 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 }
 
 
+// The same stem on the matrix pipe (fp16 output, 64 output pixels of a row per workgroup): as a GEMM it is M = pixels, N = 128,
+// K = 48, and the VALU form above spends 48 packed FMAs per pixel and lane (45 us of the 87 at bs 64).  The fp32 image and
+// the fp32 taps are both split into fp16 hi + lo, and x_hi w_hi + x_lo w_hi + x_hi w_lo is accumulated in fp32 (the dropped
+// x_lo w_lo is 2^-22 of the product): the stem stays an fp32-accurate convolution, unlike the rest of the fp16 mode whose
+// weights are rounded once.  K order: k = c*16 + kh*4 + kw as in wt, padded to 64 (two 32-deep MFMA steps).
+// Wave w owns channels [32 w, 32 w + 32) (two 16-row A tiles, taps converted once per workgroup from wt) for all four
+// 16-pixel tiles; the B fragments (pixel = column) are built from the staged patch rows: the 8 taps of a lane are two
+// consecutive (c, kh) rows x 4 kw = two 16-byte LDS reads.  LayerNorm: two-pass like the VALU form, channel sums across
+// the four waves through LDS.
+template <int RPW>   // output rows per workgroup: the tap conversion above is paid once per RPW x 64 pixels
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ img, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                        const float* __restrict__ lnb, half_t* __restrict__ out, int H,
+                                                        int W, float eps) {
+    constexpr int C0 = 128, PXB = 64;
+    __shared__ __attribute__((aligned(16))) float in_s[13][256];   // row 12: zeros (the K padding reads it)
+    __shared__ float red_s[4][PXB];
+    __shared__ float stat_s[PXB];
+    const int Ho = H / 4, Wo = W / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nwb = Wo / PXB;
+    const int wblk = blockIdx.x % nwb;
+    const int hog = (blockIdx.x / nwb) % (Ho / RPW);
+    const int b = blockIdx.x / (nwb * (Ho / RPW));
+    const int wo0 = wblk * PXB;
+    in_s[12][tid] = 0.f;
+    // ---- A fragments: lane (fr, fq) of (nt, s) holds taps k = s*32 + fq*8 + j of channel n = 32 wave + 16 nt + fr
+    half8 ah[2][2], al[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = st * 32 + fq * 8 + j;
+                const float w = k < 48 ? wt[k * C0 + wave * 32 + nt * 16 + fr] : 0.f;
+                const half_t hi = (half_t)w;
+                ah[nt][st][j] = hi;
+                al[nt][st][j] = (half_t)(w - (float)hi);
+            }
+    f32x4 bv[2], gw[2], gb[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = wave * 32 + nt * 16 + fq * 4;
+        bv[nt] = *reinterpret_cast<const f32x4*>(bias + n);
+        gw[nt] = *reinterpret_cast<const f32x4*>(lnw + n);
+        gb[nt] = *reinterpret_cast<const f32x4*>(lnb + n);
+    }
+    for (int hr = 0; hr < RPW; ++hr) {
+    const int ho = hog * RPW + hr;
+    if (hr) __syncthreads();                       // every wave is done with the previous row's patch and statistics
+    for (int i = tid; i < 12 * 64; i += 256) {     // 12 (c, kh) rows x 64 16-byte pieces
+        const int row = i >> 6, c4 = i & 63;
+        const int c = row >> 2, kh = row & 3;
+        *reinterpret_cast<f32x4*>(&in_s[row][c4 * 4]) =
+            *reinterpret_cast<const f32x4*>(img + (((long)b * 3 + c) * H + (ho * 4 + kh)) * W + wo0 * 4 + c4 * 4);
+    }
+    __syncthreads();
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        // B fragments of pixel p = mt*16 + fr: taps k0 .. k0+7 with k0 = st*32 + fq*8 = rows (k0 >> 2), (k0 >> 2) + 1 of in_s
+        half8 bh[2], bl[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int r0 = min(st * 8 + fq * 2, 12), r1 = min(st * 8 + fq * 2 + 1, 12);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&in_s[r0][(mt * 16 + fr) * 4]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&in_s[r1][(mt * 16 + fr) * 4]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = j < 4 ? x0[j & 3] : x1[j & 3];
+                const half_t hi = (half_t)x;
+                bh[st][j] = hi;
+                bl[st][j] = (half_t)(x - (float)hi);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 a = bv[nt];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nt][st], bh[st], a, 0, 0, 0);   // small terms first
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt][st], bl[st], a, 0, 0, 0);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt][st], bh[st], a, 0, 0, 0);
+            acc[mt][nt] = a;
+        }
+    }
+    // ---- LayerNorm over the 128 channels of a pixel: lane holds channels 32 wave + 16 nt + 4 fq + e of pixels mt*16 + fr
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            float a = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (pass == 1) acc[mt][nt][e] -= mean[mt];
+                    a += pass == 0 ? acc[mt][nt][e] : acc[mt][nt][e] * acc[mt][nt][e];
+                }
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            if (fq == 0) red_s[wave][mt * 16 + fr] = a;
+        }
+        __syncthreads();
+        if (tid < PXB) {
+            const float a = (red_s[0][tid] + red_s[1][tid]) + (red_s[2][tid] + red_s[3][tid]);
+            stat_s[tid] = pass == 0 ? a * (1.0f / C0) : rsqrtf(a * (1.0f / C0) + eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (pass == 0) mean[mt] = stat_s[mt * 16 + fr];
+            else rstd[mt] = stat_s[mt * 16 + fr];
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            half4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc[mt][nt][e] * rstd[mt] * gw[nt][e] + gb[nt][e]);
+            *reinterpret_cast<half4*>(out + (((long)b * Ho + ho) * Wo + wo0 + mt * 16 + fr) * C0 + wave * 32 + nt * 16 + fq * 4) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- crop pre-processing
 // One thread per destination pixel of the S x S crop (image + mask) or of the R x R crop (coordinate grid); the
 // fixed-point source coordinate is cv::warpAffine's (AB_BITS = 10, round-half-even of the double products).
@@ -616,7 +748,12 @@ extern "C" int gp_convnext_stem(const float* img, const float* w, const float* b
     const long px = (long)B * (H / 4) * (W / 4);
     gp_timing_before(s, GP_KC_SMALL, 2.0 * px * 48 * C0, (double)B * 3 * H * W * 4 + (double)px * C0 * (dtype == GP_F16 ? 2 : 4));
     dim3 grid(B * (H / 4) * (W / 4 / PXB));
-    if (dtype == GP_F16) hipLaunchKernelGGL(stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps, PXB);
+    static const bool mfma_stem = [] { const char* e = getenv("GP_STEM_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (dtype == GP_F16 && PXB == 64 && mfma_stem && (H / 4) % 4 == 0)
+        hipLaunchKernelGGL(stem_mfma_kernel<4>, dim3(B * (H / 16) * (W / 4 / 64)), dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
+    else if (dtype == GP_F16 && PXB == 64 && mfma_stem)
+        hipLaunchKernelGGL(stem_mfma_kernel<1>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
+    else if (dtype == GP_F16) hipLaunchKernelGGL(stem_kernel<half_t>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps, PXB);
     else hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (float*)out, H, W, eps, PXB);
     GP_LAUNCH_CHECK("gp_convnext_stem");
 }
