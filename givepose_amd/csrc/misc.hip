@@ -463,6 +463,88 @@ __global__ __launch_bounds__(256) void smallcin_conv3x3s2_kernel(const float* __
     }
 }
 
+// The same convolution on the matrix pipe (fp16 output, Cout % 32 == 0, Ro % 32 == 0): two output rows (64 pixels) per
+// workgroup, wave w owns channels [Cout/4 * w, ...) in 16-row A tiles.  K order inside the kernel: k' = tap * 8 + c (c padded
+// to 8), so a lane's 8 k are the <= 5 channels of ONE tap = two 16-byte reads of the staged input rows [5 rows][R + 2][8];
+// 96 = three 32-deep MFMA steps (taps 9-11 are zero).  fp32 inputs and taps are split into fp16 hi + lo and
+// x_hi w_hi + x_lo w_hi + x_hi w_lo accumulates in fp32 (see stem_mfma_kernel): fp32-accurate like the VALU form.
+template <int CIN, int NTW>   // NTW: 16-channel tiles per wave (Cout = 64 NTW)
+__global__ __launch_bounds__(256) void smallcin_conv3x3s2_mfma_kernel(const float* __restrict__ xyz4,
+                                                                     const float* __restrict__ coord2d,
+                                                                     const float* __restrict__ wt, half_t* __restrict__ y,
+                                                                     int B, int R) {
+    constexpr int RMAX = 64;
+    __shared__ __attribute__((aligned(16))) float in_s[5][RMAX + 2][8];
+    const int Ro = R / 2, Cout = 64 * NTW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x / (Ro / 2), ho0 = (blockIdx.x % (Ro / 2)) * 2;
+    // ---- stage input rows 2 ho0 - 1 .. 2 ho0 + 3, columns -1 .. R (zero outside the image), 8 channels per pixel
+    for (int i = tid; i < 5 * (R + 2); i += 256) {
+        const int sr = i / (R + 2), sc = i - sr * (R + 2);
+        const int hi = 2 * ho0 - 1 + sr, wi = sc - 1;
+        const bool ok = (unsigned)hi < (unsigned)R && (unsigned)wi < (unsigned)R;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            a = *reinterpret_cast<const f32x4*>(xyz4 + (((long)b * R + hi) * R + wi) * 4);
+            a[3] = 0.f;
+            if constexpr (CIN == 5) {
+                a[3] = coord2d[(((long)b * 2 + 0) * R + hi) * R + wi];
+                c4[0] = coord2d[(((long)b * 2 + 1) * R + hi) * R + wi];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&in_s[sr][sc][0]) = a;
+        *reinterpret_cast<f32x4*>(&in_s[sr][sc][4]) = c4;
+    }
+    // ---- A fragments: lane (fr, fq) of (nt, st): channel n = (wave * NTW + nt) * 16 + fr, k' = st*32 + fq*8 + j = tap (4 st + fq), c = j
+    half8 ah[NTW][3], al[NTW][3];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int tap = st * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = (tap < 9 && j < CIN) ? wt[(j * 9 + tap) * Cout + (wave * NTW + nt) * 16 + fr] : 0.f;
+                const half_t hi = (half_t)w;
+                ah[nt][st][j] = hi;
+                al[nt][st][j] = (half_t)(w - (float)hi);
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int p = mt * 16 + fr, ro = p >> 5, wo = p & 31;   // pixel of this lane's B column (Ro == 32: one row = 2 tiles)
+        half8 bh[3], bl[3];
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int tap = min(st * 4 + fq, 8), kh = tap / 3, kw = tap - kh * 3;
+            const float* src = &in_s[2 * ro + kh][2 * wo + kw][0];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = j < 4 ? x0[j & 3] : x1[j & 3];
+                const half_t hi = (half_t)x;
+                bh[st][j] = hi;
+                bl[st][j] = (half_t)(x - (float)hi);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nt][st], bh[st], a, 0, 0, 0);   // small terms first
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt][st], bl[st], a, 0, 0, 0);
+            }
+#pragma unroll
+            for (int st = 0; st < 3; ++st) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nt][st], bh[st], a, 0, 0, 0);
+            half4 o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3]};
+            *reinterpret_cast<half4*>(y + (((long)b * Ro + ho0 + ro) * Ro + wo) * Cout + (wave * NTW + nt) * 16 + fq * 4) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------- ViT-style map encoder pieces
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ xyz4, T* __restrict__ out, int B, int R,
@@ -854,7 +936,11 @@ static int launch_smallcin(const float* xyz4, const float* coord2d, const float*
     const long pix = (long)B * (R / 2) * (R / 2);
         const size_t lds = (size_t)CIN * 9 * Cout * sizeof(float);
     gp_timing_before(s, GP_KC_SMALL, 2.0 * pix * CIN * 9 * Cout, (double)B * R * R * CIN * 4 + (double)pix * Cout * (dtype == GP_F16 ? 2 : 4));
-    if (dtype == GP_F16)
+    static const bool mfma = [] { const char* e = getenv("GP_SMALLCIN_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (dtype == GP_F16 && mfma && R == 64 && (Cout == 128 || Cout == 256)) {   // 64 x 64 maps -> 32 x 32: two output rows per workgroup
+        if (Cout == 128) hipLaunchKernelGGL((smallcin_conv3x3s2_mfma_kernel<CIN, 2>), dim3(B * (R / 4)), dim3(256), 0, s, xyz4, coord2d, w, (half_t*)y, B, R);
+        else hipLaunchKernelGGL((smallcin_conv3x3s2_mfma_kernel<CIN, 4>), dim3(B * (R / 4)), dim3(256), 0, s, xyz4, coord2d, w, (half_t*)y, B, R);
+    } else if (dtype == GP_F16)
         hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<half_t, CIN>), dim3(cdiv(pix / 4, 256 / (Cout / 4))), dim3(256), lds, s, xyz4, coord2d, w, (half_t*)y, B, R, Cout);
     else
         hipLaunchKernelGGL((smallcin_conv3x3s2_kernel<float, CIN>), dim3(cdiv(pix / 4, 256 / (Cout / 4))), dim3(256), lds, s, xyz4, coord2d, w, (float*)y, B, R, Cout);
