@@ -529,6 +529,27 @@ def test_xyz_out_pointwise_smallcin(dt):
     assert rel_err(out3, F.conv2d(xin[:, :3], w3c, None, stride=2, padding=1).permute(0, 2, 3, 1)) < TOL[dt]
 
 
+def test_smallcin_conv_mfma_path():
+    """R = 64 (the PoseNet map size) takes the MFMA form of the tiny-Cin 3x3 s2 convs in fp16: fp32 inputs and taps split into
+    fp16 hi + lo inside the kernel, so it must be as close to the fp32 formula as the VALU form (fp16 output rounding only)."""
+    o = ops()
+    B, R = 3, 64
+    xyz, coord = rnd(B, R, R, 3, seed=57), rnd(B, 2, R, R, seed=58)
+    nhwc4 = torch.cat([xyz, torch.zeros(B, R, R, 1)], -1).reshape(B * R * R, 4).cuda()
+    xin = torch.cat([xyz.permute(0, 3, 1, 2), coord], 1)
+    for (cin, cout, seed) in ((5, 128, 59), (3, 256, 60), (3, 128, 61)):
+        w = rnd(cout, cin, 3, 3, seed=seed, scale=(9 * cin) ** -0.5)
+        ref = F.conv2d(xin[:, :cin].double(), w.double(), None, stride=2, padding=1).permute(0, 2, 3, 1)
+        out = torch.empty(B, R // 2, R // 2, cout, dtype=torch.float16, device="cuda")
+        wp = w.reshape(cout, 9 * cin).t().contiguous().cuda()
+        if cin == 5:
+            o.pnp_conv1(nhwc4, coord.cuda(), wp, out, B, R)
+        else:
+            o.xyz_conv3x3_s2(nhwc4, wp, out, B, R)
+        d = (out.cpu().double() - ref).abs()
+        assert float(d.max()) <= 2.0 ** -10 * max(1.0, float(ref.abs().max())) and float(d.mean()) < 2e-4, (cin, cout, float(d.max()), float(d.mean()))
+
+
 def test_size_head_golden(golden):
     """vs the reference SizeHead output (BN folded on the host) + mean-size residual."""
     from givepose_amd import synth
