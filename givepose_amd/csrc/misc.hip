@@ -689,31 +689,56 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------- SizeHead
-// kernel 1: grid (B, F/16): global max over HW -> LDS, then 16 hidden units (BN folded, ReLU) -> scratch (B,F)
+// kernel 0: grid (B, C/256): AdaptiveMaxPool over HW -> pooled (B, C) fp32.  (Round 1 repeated this pool in every one of the
+// F/16 workgroups of an image: 32 x the 128-KB map per image at bs 64, 40 us; now 8 MB once.)
 template <typename T>
-__global__ __launch_bounds__(256) void size_hidden_kernel(const T* __restrict__ feat, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, float* __restrict__ hid,
-                                                          int HW, int C, int F) {
+__global__ __launch_bounds__(256) void size_pool_kernel(const T* __restrict__ feat, float* __restrict__ pooled, int HW, int C) {
+    const int b = blockIdx.x, cq = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;   // 4 channels per lane, 4 pixel quarters
+    __shared__ float m_s[4][64][4];
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (cq * 4 < C) {
+        const T* p = feat + (long)b * HW * C + cq * 4;
+        for (int px = part; px < HW; px += 4) {
+            if constexpr (sizeof(T) == 2) {
+                const half4 h = *reinterpret_cast<const half4*>(p + (long)px * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], (float)h[e]);
+            } else {
+                const f32x4 h = *reinterpret_cast<const f32x4*>(p + (long)px * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], h[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m_s[part][threadIdx.x & 63][e] = m[e];
+    __syncthreads();
+    if (part == 0 && cq * 4 < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            pooled[(long)b * C + cq * 4 + e] = fmaxf(fmaxf(m_s[0][threadIdx.x][e], m_s[1][threadIdx.x][e]), fmaxf(m_s[2][threadIdx.x][e], m_s[3][threadIdx.x][e]));
+    }
+}
+
+// kernel 1: grid (B, F/16): pooled row -> LDS, then 16 hidden units (BN folded, ReLU) -> hid (B,F)
+__global__ __launch_bounds__(256) void size_hidden_kernel(const float* __restrict__ pooled_g, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, float* __restrict__ hid, int C, int F) {
     extern __shared__ float pooled[];  // [C]
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c4 = tid; c4 < C / 4; c4 += 256) {
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        const T* p = feat + (long)b * HW * C + c4 * 4;
-        for (int px = 0; px < HW; ++px)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], (float)p[(long)px * C + e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pooled[c4 * 4 + e] = m[e];
-    }
+    for (int c = tid; c < C; c += 256) pooled[c] = pooled_g[(long)b * C + c];
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const int f0 = blockIdx.y * 16 + wave * 4;
+    for (int c = lane; c < C; c += 64) {          // four hidden units side by side: four independent load streams
+        const float x = pooled[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaf(x, w1[(long)(f0 + j) * C + c], a[j]);
+    }
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int f = blockIdx.y * 16 + wave * 4 + j;
-        if (f >= F) break;
-        float a = 0.f;
-        for (int c = lane; c < C; c += 64) a += pooled[c] * w1[(long)f * C + c];
-        a = group_sum(a, 64);
-        if (lane == 0) hid[(long)b * F + f] = fmaxf(a + b1[f], 0.f);
+        const float v = group_sum(a[j], 64);
+        if (lane == 0) hid[(long)b * F + f0 + j] = fmaxf(v + b1[f0 + j], 0.f);
     }
 }
 
@@ -967,8 +992,10 @@ extern "C" int gp_size_head(const void* feat, const float* w1, const float* b1, 
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_SMALL, 2.0 * B * (C * F + 3 * F), (double)B * HW * C * (dtype == GP_F16 ? 2 : 4));
     const size_t lds = (size_t)C * sizeof(float);
-    if (dtype == GP_F16) hipLaunchKernelGGL(size_hidden_kernel<half_t>, dim3(B, F / 16), dim3(256), lds, s, (const half_t*)feat, w1, b1, scratch, HW, C, F);
-    else hipLaunchKernelGGL(size_hidden_kernel<float>, dim3(B, F / 16), dim3(256), lds, s, (const float*)feat, w1, b1, scratch, HW, C, F);
+    float* pooled = scratch + (long)B * F;         // scratch: (B, F) hidden units, then (B, C) pooled maxima
+    if (dtype == GP_F16) hipLaunchKernelGGL(size_pool_kernel<half_t>, dim3(B, cdiv(C, 256)), dim3(256), 0, s, (const half_t*)feat, pooled, HW, C);
+    else hipLaunchKernelGGL(size_pool_kernel<float>, dim3(B, cdiv(C, 256)), dim3(256), 0, s, (const float*)feat, pooled, HW, C);
+    hipLaunchKernelGGL(size_hidden_kernel, dim3(B, F / 16), dim3(256), lds, s, pooled, w1, b1, scratch, C, F);
     hipLaunchKernelGGL(size_out_kernel, dim3(B), dim3(64), 0, s, scratch, w2, b2, mean_size, size, F);
     GP_LAUNCH_CHECK("gp_size_head");
 }

@@ -366,6 +366,8 @@ def xyz_conv3x3_s2(xyz4, w, out, B, R):
 
 def size_head(feat, w1, b1, w2, b2, mean_size, out, scratch):
     B, HW, C = feat.shape
+    if scratch.numel() < B * (w1.shape[0] + C):
+        raise ValueError("size_head: scratch needs B * (F + C) floats")
     check(_L().gp_size_head(_ptr(_contig(feat, "feat")), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mean_size), _ptr(out),
                             _ptr(scratch), B, HW, C, w1.shape[0], dtype_code(feat.dtype), _stream()), "gp_size_head")
     return out

@@ -266,7 +266,7 @@ class PoseNet(nn.Module):
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
         chunks = max(ops.groupnorm_chunks(B, r * r) for r in (8, 16, 32, 64))
-        buf["gn_partial"], buf["size_scratch"] = f(B * max(chunks, R * R // 64) * 32 * 2), f(B * cfg.feat_ts)
+        buf["gn_partial"], buf["size_scratch"] = f(B * max(chunks, R * R // 64) * 32 * 2), f(B * (cfg.feat_ts + (512 if cfg.main_backbone == "resnet34" else cfg.convnext_dims[-1])))
         buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["mask_out"], buf["size"] = f(B, 1, R, R), f(B, 3)

@@ -229,7 +229,7 @@ int gp_xyz_conv3x3_s2(const float* xyz4, const float* w, void* y, int B, int R, 
 
 /* SizeHead (network/pose_head.py:30-42) + mean-size residual (network/PoseNet.py:199-202):
  * feat (B,HW,C); w1 (F,C) / b1 (F) with eval BatchNorm folded in; w2 (3,F), b2 (3);
- * out size (B,3) fp32 = head + mean_size/||mean_size||; scratch: B*F floats. */
+ * out size (B,3) fp32 = head + mean_size/||mean_size||; scratch: B*(F + C) floats (hidden units, pooled maxima). */
 int gp_size_head(const void* feat, const float* w1, const float* b1, const float* w2, const float* b2,
                  const float* mean_size, float* size, float* scratch, int B, int HW, int C, int F, int dtype,
                  void* stream);

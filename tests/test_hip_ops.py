@@ -566,7 +566,7 @@ def test_size_head_golden(golden):
     ms = torch.tensor([[0.1, 0.2, 0.3]] * B)
     out = torch.empty(B, 3, device="cuda")
     o.size_head(x.permute(0, 2, 3, 1).reshape(B, 64, 1024).contiguous().cuda(), w1.cuda(), b1.cuda(),
-                sd["conv2.weight"].squeeze(-1).contiguous().cuda(), sd["conv2.bias"].cuda(), ms.cuda(), out, torch.empty(B * 128, device="cuda"))
+                sd["conv2.weight"].squeeze(-1).contiguous().cuda(), sd["conv2.bias"].cuda(), ms.cuda(), out, torch.empty(B * (128 + 1024), device="cuda"))
     ref = torch.from_numpy(z["expected"]) + ms / ms.norm(dim=1, keepdim=True)
     assert float((out.cpu() - ref).abs().max()) < 2e-5
 
