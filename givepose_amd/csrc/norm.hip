@@ -895,6 +895,94 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
     }
 }
 
+// The same pass with the 1x1 out layer on the matrix pipe (fp16 input, C = 256, GELU): per 16 pixels a wave normalises and
+// activates its pixels' channels in the MFMA B layout (lane (pixel m, fq) owns channels ks*32 + fq*8 .. +8 of K step ks: one
+// 16-byte load each), splits them into fp16 hi + lo, and 8 x 3 MFMAs against the (3 -> 16 rows, fp16 hi + lo) out-layer weights
+// do the 3 x 256 dot products and their reduction in fp32 accuracy: no per-pixel cross-lane sums, no fp32 dot FMAs.
+// scale / shift per channel in LDS.
+__global__ __launch_bounds__(256, 4) void gn_apply_xyz_mfma_kernel(const half_t* __restrict__ x, const float* __restrict__ partial,
+                                                                const float* __restrict__ w, const float* __restrict__ bb,
+                                                                const float* __restrict__ ow, const float* __restrict__ ob,
+                                                                float* __restrict__ out_nchw, float* __restrict__ out_nhwc4,
+                                                                int HW, int G, int chunks, float inv_count, float eps, int GN_PXB) {
+    constexpr int C = 256, KS = C / 32;
+    __shared__ float st[256][2];
+    __shared__ __attribute__((aligned(16))) float sc_s[C], sh_s[C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
+    // out-layer weights as A fragments in LDS ([ks][hi / lo][lane] x 16 B; 64 registers otherwise): row n = fr (3 real rows),
+    // k = ks*32 + fq*8 + j; fp16 hi + lo of the fp32 weights.  Wave w builds K steps 2w, 2w + 1.
+    __shared__ __attribute__((aligned(16))) half8 a_s[KS][2][64];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ks = wave * 2 + kk;
+        half8 hi8, lo8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = fr < 3 ? ow[fr * C + ks * 32 + fq * 8 + j] : 0.f;
+            const half_t hi = (half_t)v;
+            hi8[j] = hi;
+            lo8[j] = (half_t)(v - (float)hi);
+        }
+        a_s[ks][0][lane] = hi8;
+        a_s[ks][1][lane] = lo8;
+    }
+    gn_finalize(partial, b, chunks, G, inv_count, eps, st);
+    {
+        const int cpg = C / G, g = tid / cpg;
+        const float s = st[g][1] * w[tid];
+        sc_s[tid] = s;
+        sh_s[tid] = bb[tid] - st[g][0] * s;
+    }
+    __syncthreads();
+    const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
+    for (int pb = p0 + wave * 16; pb < p1; pb += 64) {
+        const int p = pb + fr;
+        const bool ok = p < p1;
+        const half_t* xp = x + ((long)b * HW + (ok ? p : p0)) * C + fq * 8;
+        half8 xv[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xv[ks] = *reinterpret_cast<const half8*>(xp + ks * 32);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = ks * 32 + fq * 8;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_s + c0), s1 = *reinterpret_cast<const f32x4*>(sc_s + c0 + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_s + c0), h1 = *reinterpret_cast<const f32x4*>(sh_s + c0 + 4);
+            f32x2 v[4];
+            v[0] = f32x2{fmaf((float)xv[ks][0], s0[0], h0[0]), fmaf((float)xv[ks][1], s0[1], h0[1])};
+            v[1] = f32x2{fmaf((float)xv[ks][2], s0[2], h0[2]), fmaf((float)xv[ks][3], s0[3], h0[3])};
+            v[2] = f32x2{fmaf((float)xv[ks][4], s1[0], h1[0]), fmaf((float)xv[ks][5], s1[1], h1[1])};
+            v[3] = f32x2{fmaf((float)xv[ks][6], s1[2], h1[2]), fmaf((float)xv[ks][7], s1[3], h1[3])};
+            gelu_poly2_xn<4>(v);
+            half8 a16, a16l;   // activations as fp16 hi + lo as well: the fused pass keeps the fp32 accuracy of the VALU form
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const half_t hi = (half_t)v[i][e];
+                    a16[2 * i + e] = hi;
+                    a16l[2 * i + e] = (half_t)(v[i][e] - (float)hi);
+                }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_s[ks][1][lane], a16, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_s[ks][0][lane], a16l, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_s[ks][0][lane], a16, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // one K step's four GELU chains at a time (all eight in flight: 254 registers)
+        }
+        // D: lane (pixel fr, fq) holds out rows fq*4 + e: the three outputs live in the fq == 0 lanes
+        if (fq == 0 && ok) {
+            const long row = (long)b * HW + p;
+            const float d0 = acc[0] + b0, d1 = acc[1] + b1, d2 = acc[2] + b2;
+            out_nchw[((long)b * 3 + 0) * HW + p] = d0;
+            out_nchw[((long)b * 3 + 1) * HW + p] = d1;
+            out_nchw[((long)b * 3 + 2) * HW + p] = d2;
+            *reinterpret_cast<f32x4*>(out_nhwc4 + row * 4) = f32x4{d0, d1, d2, 0.f};
+        }
+    }
+}
+
 bool ct_ok(int C, int esz) {
     const int vec = 16 / esz;
     if (C % vec) return false;
@@ -1048,7 +1136,10 @@ extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const
     const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW)), pxb = gn_apply_pxb(B, HW);
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
-    if (dtype == GP_F16)
+    static const bool mfma = [] { const char* e = getenv("GP_GNXYZ_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (dtype == GP_F16 && C == 256 && act == GP_ACT_GELU && 256 % G == 0 && mfma)
+        hipLaunchKernelGGL(gn_apply_xyz_mfma_kernel, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, G, chunks, inv_count, eps, pxb);
+    else if (dtype == GP_F16)
         hipLaunchKernelGGL(gn_apply_xyz_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, C, G, act, chunks, inv_count, eps, pxb);
     else
         hipLaunchKernelGGL(gn_apply_xyz_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, C, G, act, chunks, inv_count, eps, pxb);
