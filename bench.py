@@ -46,8 +46,10 @@ PEAK_HBM_GBS = 8000.0
 # measured against the reference golden vectors (B in {1,4,5}) and the oracle at the bench shape (worst crop of 64):
 # tests/test_hip_posenet.py::test_fp32_bs64_matches_oracle / test_fp16_bs64_close_to_oracle, max abs error
 VS_REFERENCE = {"f32": {"rot": 7.3e-5, "trans": 5.6e-6, "size": 1.6e-5, "meets_1e-4": True},
-                "f16": {"rot": 3.6e-2, "trans": 4.3e-3, "size": 1.5e-2, "meets_1e-4": False,
-                        "note": "fp16 operands cannot meet 1e-4: rounding the weights alone gives 1.5e-3 (tests/precision_model.py)"}}
+                "f16": {"rot": 4.5e-2, "rot_median_over_crops": 3.5e-3, "rot_p90_over_crops": 9e-3, "trans": 3.2e-3, "size": 1.3e-2,
+                        "meets_1e-4": False,
+                        "note": "fp16 operands cannot meet 1e-4: rounding the weights alone gives 1.5e-3 (tests/precision_model.py); "
+                                "the worst-crop maximum of rot is chaotic (2.3e-2 ... 6.2e-2 across numerically equivalent builds)"}}
 
 
 def usable_cores():

@@ -10,15 +10,16 @@ LIB = os.path.join(HERE, "libgivepose_hip.so")
 SOURCES = ["runtime.hip", "gemm.hip", "mlp.hip", "dcnv3.hip", "dcnv3_any.hip", "norm.hip", "misc.hip", "scalenet.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-value"]
-# GP_NO_PACKED_FP32=1: build without packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  They
-# are the victim half of the cross-wave corruption on MI355X (a wave's v_pk_fma_f32 ... op_sel beside another wave's dense
-# MFMA stream; scripts/repro/pkfma_beside_mfma.hip: 0 failures once the victim uses scalar FMAs), and this
-# switch removes every one of them from the library (checked: 0 in the disassembly) at a measured cost of 2.3 % of the
-# step (8 257 against 8 064 us of kernels, 10.16 against 10.4 k images/s).  The default build keeps them: the one
-# aggressor kernel is gone and the overlapped mode is clean in 4 650 stress slot-runs.  (The x86 host pass ignores the
-# unknown target feature with a warning.)
-FLAGS += os.environ.get("GP_EXTRA_HIPCC_FLAGS", "").split()   # investigation builds (e.g. -DGP_WREG_STAMPS), never the shipped library
-if os.environ.get("GP_NO_PACKED_FP32") == "1":
+# The library is built WITHOUT packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  On MI355X a
+# wave's `v_pk_fma_f32 ... op_sel` results come out wrong (one 16-lane pass, low half of one packed register) while another
+# wave on the same SIMD issues MFMAs + ds_read_b128 (scripts/repro/pkfma_beside_mfma.hip: 27-99 % of the victim
+# launches, 0 with scalar FMAs).  Round 2 first removed the one aggressor kernel it knew and kept the packed ops (they were
+# worth 2.3 % then); later in the round a new small-footprint MFMA kernel with a packed GELU corrupted ITSELF with batches in
+# flight (8 of 150 stress repetitions, 0 once its GELU was plain VALU), and a low residual rate stayed on sensitive boxes
+# (1 of 32 runs of the bs-64 stress test against 0 of 32 for this build).  With the GELU of the large GEMMs on plain FMAs by
+# then, this build is no slower (10.81 against 10.75 k images/s, same box).  tests/test_abi.py checks the disassembly.
+# GP_PACKED_FP32=1 re-enables them for A/B runs.  (The x86 host pass ignores the unknown target feature with a warning.)
+if os.environ.get("GP_PACKED_FP32") != "1":
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wno-unknown-warning-option"]
 
 

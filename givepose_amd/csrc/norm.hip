@@ -956,7 +956,15 @@ __global__ __launch_bounds__(256, 4) void gn_apply_xyz_mfma_kernel(const half_t*
             v[1] = f32x2{fmaf((float)xv[ks][2], s0[2], h0[2]), fmaf((float)xv[ks][3], s0[3], h0[3])};
             v[2] = f32x2{fmaf((float)xv[ks][4], s1[0], h1[0]), fmaf((float)xv[ks][5], s1[1], h1[1])};
             v[3] = f32x2{fmaf((float)xv[ks][6], s1[2], h1[2]), fmaf((float)xv[ks][7], s1[3], h1[3])};
-            gelu_poly2_xn<4>(v);
+            {   // GELU as 12 slices of one inline-asm v_fma_f32 / v_mul_f32 per element (common.hpp): a fixed instruction sequence
+                f32x2 gx[4], gt[4], gp[4];
+                float c1v = GELU_H[1];
+                asm volatile("" : "+v"(c1v));
+                static_for<0, GELU_SLICES>([&](auto sc) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gelu_poly2_slice<decltype(sc)::value>(v[i], gx[i], gt[i], gp[i], c1v);
+                });
+            }
             half8 a16, a16l;   // activations as fp16 hi + lo as well: the fused pass keeps the fp32 accuracy of the VALU form
 #pragma unroll
             for (int i = 0; i < 4; ++i)

@@ -26,3 +26,5 @@ y = F.gelu(F.group_norm(xr.permute(0, 2, 1), 32, gw.double(), gb.double(), 1e-5)
 ref = (y @ ow.double().t() + ob.double()).permute(0, 2, 1).reshape(4, 3, R, R)
 d = (nchw[:4].cpu().double() - ref).abs()
 print(f"mfma={os.environ.get('GP_GNXYZ_MFMA', '1')}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us; vs fp64: max abs {d.max():.3e}, mean abs {d.mean():.3e}; nhwc4 == nchw: {torch.equal(nhwc4.view(B, R * R, 4)[..., :3].permute(0, 2, 1).reshape(B, 3, R, R), nchw)}")
+i = int(d.flatten().argmax()); bi, ci, pi = i // (3 * R * R), (i // (R * R)) % 3, i % (R * R)
+print(f"  worst element: crop {bi} out {ci} pixel {pi}: got {nchw[bi, ci].flatten()[pi].item():.6f} want {ref[bi, ci].flatten()[pi].item():.6f}; row max|pre-act| {y[bi, pi].abs().max().item():.3f}; count > 1e-4: {int((d > 1e-4).sum())}")

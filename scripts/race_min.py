@@ -3,8 +3,8 @@
 Stream A loops an AGGRESSOR launch, stream B loops a VICTIM launch into rotating output buffers; after every round the
 victim outputs are compared bitwise with a reference computed alone.  Nothing is shared between the two streams.
 
-  AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | v16 | mlp | torchmm | none
-  VIC = k3 | gnapply | gn | torchfma            (the scalar-FMA victim of r02_race6.log was a build switch of the investigation;
+  AGG = v1 | v1dbgNN | v1small | v7 | v7big | v4 | v8 | v10 | v13 | v16 | mlp | gnxyz | stem | torchmm | none
+  VIC = k3 | gnapply | gn | deconv | torchfma            (the scalar-FMA victim of r02_race6.log was a build switch of the investigation;
                                                  scripts/repro/pkfma_beside_mfma.hip -DNOPK is its stand-alone form)
 The v1* aggressors are the round-1 register-staged `gemm_kernel`, which no longer exists in the library: run them
 against a build of the round-1 sources (git show 35dfc42:givepose_amd/csrc/<file> for the six .hip files + common.hpp,
@@ -39,6 +39,16 @@ if AGG in ("v10", "v8", "v7big", "v4"):
 if AGG == "v16":     # weights-in-registers GEMM (K = 512): stage-2 fc1 shape
     ex, ew, eb = rnd(16384, 512).half().to(dev), (rnd(2048, 512) * 0.04).half().to(dev), rnd(2048).to(dev)
     eout = torch.empty(16384, 2048, dtype=torch.float16, device=dev)
+if AGG == "gnxyz":   # GroupNorm + GELU + out layer of the xyz heads (MFMA form unless GP_GNXYZ_MFMA=0)
+    from givepose_amd._lib import ACT_GELU
+    qx = rnd(64, 4096, 256).half().to(dev)
+    qxf = qx.float().view(64, 64, 64, 32, 8)
+    qpart = torch.stack([qxf.sum((2, 4)), (qxf * qxf).sum((2, 4))], -1).contiguous().view(-1)
+    qgw, qgb, qow, qob = rnd(256).to(dev), rnd(256).to(dev), (rnd(3, 256) * 0.06).to(dev), rnd(3).to(dev)
+    qn, q4 = torch.empty(64, 3, 64, 64, device=dev), torch.empty(64 * 4096, 4, device=dev)
+if AGG == "stem":
+    simg, sw_, sb_ = rnd(64, 3, 256, 256).to(dev), (rnd(48, 128) * 0.14).to(dev), rnd(128).to(dev)
+    slw, slb, sout = rnd(128).to(dev), rnd(128).to(dev), torch.empty(64, 64, 64, 128, dtype=torch.float16, device=dev)
 if AGG == "v13":
     dx, dw = rnd(8, 32, 32, 256).half().to(dev), (rnd(256, 2304) * 0.02).half().to(dev)
     dout = torch.empty(8, 32, 32, 256, dtype=torch.float16, device=dev)
@@ -62,6 +72,10 @@ def aggressor():
         ops.gemm(cx, cw, cout, bias=cb, epilogue=EPI_LRELU, variant={"v10": 10, "v8": 8, "v7big": 7, "v4": 4}[AGG], splitk=1)
     elif AGG == "v16":
         ops.gemm(ex, ew, eout, bias=eb, epilogue=1, variant=16, splitk=1)
+    elif AGG == "gnxyz":
+        ops.groupnorm_apply_xyz(qx, qgw, qgb, qow, qob, qn, q4, 32, ACT_GELU, qpart)
+    elif AGG == "stem":
+        ops.convnext_stem(simg, sw_, sb_, slw, slb, sout)
     elif AGG == "v13":
         ops.conv2d_nhwc(dx, dw, 3, 3, 1, 1, out=dout, variant=13)
     elif AGG == "mlp":
@@ -84,7 +98,15 @@ gpart = torch.empty(64 * 64 * 32 * 2, dtype=torch.float32, device=dev)
 gao = [torch.empty_like(gx) for _ in range(NV)] if VIC == "gnapply" else None
 
 
+if VIC == "deconv":    # the xyz heads' deconv-as-GEMM (128x128 tile, fp32 output: generic epilogue)
+    vx, vw = rnd(4096, 1024).half().to(dev), (rnd(2304, 1024) * 0.03).half().to(dev)
+    vouts = [torch.empty(4096, 2304, device=dev) for _ in range(NV)]
+
+
 def victim(i):
+    if VIC == "deconv":
+        ops.gemm(vx, vw, vouts[i], variant=7, splitk=1)
+        return vouts[i]
     if VIC == "k3":
         ops.pointwise_k3(xyz4, kw_, kb_, outs[i])
         return outs[i]

@@ -157,9 +157,14 @@ def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
     print("fp16 bs64", repr(use_dcn), err)
     assert torch.equal(out["mask"].cpu(), ref["mask"])
     assert err["nocs_coor"] < 2e-2 and err["ivfc_coor"] < 2e-2
-    # worst crop of 64 (measured 3.6e-2 on R: the rot6d -> R normalisation amplifies the fp16 error of the least
-    # well-conditioned crop); fp16 operands cannot meet 1e-4 at all -- tests/precision_model.py, DESIGN.md 5c
-    assert err["rot"] < 6e-2 and err["size"] < 3e-2
+    # fp16 operands cannot meet 1e-4 at all -- tests/precision_model.py, DESIGN.md 5c.  Per crop the error of R is small
+    # (median 3.5e-3, 90th percentile 9e-3 over the 64 crops); the rot6d -> R normalisation amplifies the fp16 error of the
+    # one or two least well-conditioned crops, and THAT maximum is chaotic: numerically equivalent builds (e.g. the fp32-accurate
+    # stem on VALU or on MFMA) move it between 2.3e-2 and 6.2e-2.  So: the distribution tightly, the maximum loosely.
+    per_crop = (out["rot"].cpu() - ref["rot"]).abs().reshape(out["rot"].shape[0], -1).max(1).values.sort().values
+    print("fp16 bs64 per-crop |dR|: median %.4f p90 %.4f max %.4f" % (float(per_crop[32]), float(per_crop[57]), float(per_crop[-1])))
+    assert float(per_crop[32]) < 8e-3 and float(per_crop[57]) < 2e-2
+    assert err["rot"] < 1.2e-1 and err["size"] < 3e-2
     assert err["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max()))
 
 
