@@ -168,6 +168,19 @@ def main():
         "vs_reference": VS_REFERENCE[args.dtype],
     }
 
+    # the timed steps overlapped NF batches: replay every slot strictly alone (same hipGraph, same kernels) and compare the poses
+    # bit for bit -- `value` is only worth reporting if overlapping changed nothing
+    if NF > 1 and world == 1:
+        torch.cuda.synchronize(dev)
+        over = [run.result(i).clone() for i in range(NF)]
+        same = True
+        for i in range(NF):
+            o = net.forward_device(run.statics[i], dev, slot=i, wait=True)
+            torch.cuda.synchronize(dev)
+            same = same and torch.equal(gd.pack_poses(o["rot"], o["trans"], o["size"]), over[i])
+        line["overlap_check"] = {"slots": NF, "poses_bitwise_equal_to_serial_replay": bool(same)}
+        if not same:
+            note("WARNING: overlapped batches did not reproduce the serial replay bit for bit")
     if rank == 0:
         note(f"timed region: {value:.1f} images/s")
     # ---------------- the same K steps strictly one after the other, on a net BUILT for one batch in flight
