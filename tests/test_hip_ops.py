@@ -479,6 +479,43 @@ def test_stem(dt):
     assert rel_err(out, ref) < TOL[dt]
 
 
+def test_stem_mfma_forms_fp32_accurate():
+    """fp16-output stem on MFMA (fp16 hi + lo split of image and taps): four rows per workgroup (H/4 % 4 == 0) and one row
+    per workgroup; against the fp64 formula the only error left is the fp16 rounding of the output."""
+    o = ops()
+    for (B, H) in ((2, 64), (1, 72), (3, 8)):
+        img = rnd(B, 3, H, 256, seed=141)
+        w, b = rnd(128, 3, 4, 4, seed=142, scale=48 ** -0.5), rnd(128, seed=143, scale=0.1)
+        lw, lb = 1 + 0.1 * rnd(128, seed=144), 0.1 * rnd(128, seed=145)
+        ref = F.layer_norm(F.conv2d(img.double(), w.double(), b.double(), stride=4).permute(0, 2, 3, 1), (128,), lw.double(), lb.double(), 1e-6)
+        out = torch.empty(B, H // 4, 64, 128, dtype=torch.float16, device="cuda")
+        o.convnext_stem(img.cuda(), w.reshape(128, 48).t().contiguous().cuda(), b.cuda(), lw.cuda(), lb.cuda(), out)
+        d = (out.cpu().double() - ref).abs()
+        assert float(d.max()) <= 2.0 ** -10 * max(1.0, float(ref.abs().max())) and float(d.mean()) < 2.5e-4, (B, H, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("HW", [4096, 1024, 1600])
+def test_groupnorm_apply_xyz(HW):
+    """GroupNorm apply + GELU + the 1x1 out layer in one pass from the conv epilogue's 64-row statistics (fp16 C = 256: the MFMA
+    form with hi/lo split operands; fp32: the VALU form): both write the NCHW and the (rows, 4) maps, fp32-accurate."""
+    o = ops()
+    from givepose_amd._lib import ACT_GELU
+    B, C, G = 3, 256, 32
+    for dt in (torch.float16, torch.float32):
+        x = q(rnd(B, HW, C, seed=151), dt)
+        gw, gb = 1 + 0.1 * rnd(C, seed=152), 0.1 * rnd(C, seed=153)
+        ow, ob = rnd(3, C, seed=154, scale=C ** -0.5), rnd(3, seed=155, scale=0.1)
+        xf = x.view(B, HW // 64, 64, G, C // G)
+        part = torch.stack([xf.sum((2, 4)), (xf * xf).sum((2, 4))], -1).contiguous().view(-1).cuda()
+        y = F.gelu(F.group_norm(x.double().permute(0, 2, 1), G, gw.double(), gb.double(), 1e-5).permute(0, 2, 1))
+        ref = y @ ow.double().t() + ob.double()                                                    # (B, HW, 3)
+        nchw, nhwc4 = torch.empty(B, 3, HW, device="cuda"), torch.full((B * HW, 4), 7.0, device="cuda")
+        o.groupnorm_apply_xyz(x.to("cuda", dt), gw.cuda(), gb.cuda(), ow.cuda(), ob.cuda(), nchw, nhwc4, G, ACT_GELU, part)
+        d = (nchw.cpu().double().permute(0, 2, 1) - ref).abs()
+        assert float(d.max()) < 2e-4 and float(d.mean()) < 3e-5, (dt, HW, float(d.max()), float(d.mean()))
+        assert torch.equal(nhwc4.view(B, HW, 4)[..., :3].permute(0, 2, 1), nchw) and float(nhwc4[:, 3].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_upsample_and_col2im(dt):
     o = ops()
