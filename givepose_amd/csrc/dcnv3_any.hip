@@ -5,7 +5,8 @@
 // axis, any group_channels, and there is a backward -- and its own test (network/ops_dcnv3/test.py:35-170, 262-265)
 // exercises double and channel counts such as 1, 30, 71.  These two kernels are that breadth:
 //   * dcnv3_any_fwd_kernel: the arithmetic of dcnv3_im2col_cuda.cuh:216-282 (+ :32-80) with opmath = double for double,
-//     float otherwise; one thread per output scalar, channel fastest (coalesced rows of D);
+//     float otherwise.  One WAVEFRONT per (output pixel, group): lane t resolves tap t once, the tap loop broadcasts it and
+//     the lanes walk the D channels (coalesced runs);
 //   * dcnv3_any_bwd_kernel: dcnv3_im2col_cuda.cuh:386-487 (+ :82-140).  One WAVEFRONT per (output pixel, group): the 64
 //     lanes walk the D channels; grad_input is scattered with atomics (as the reference does), the per-tap grad_offset /
 //     grad_mask partials are reduced over the channels with wave shuffles (the reference: a shared-memory tree over a
@@ -24,46 +25,82 @@ struct AnyKP {
     long rows;   // N * Ho * Wo
 };
 
+// Forward, any geometry / dtype.  One WAVEFRONT per (output pixel, group) -- the mapping of the backward below and of the hot
+// kernel in dcnv3.hip, not the reference's thread per output scalar: the sampling geometry of a (pixel, group, tap) does not
+// depend on the channel, so lane t works out tap t ONCE per wave -- location, the four corner weights (zero for a corner
+// outside the image, the fetch then goes to a clamped address, so there is no branch between the loads), the mask weight and
+// the element offsets of the corners -- and the tap loop broadcasts those eight numbers from the owner lane (the lane index
+// is wave-uniform: v_readlane, no LDS) while the 64 lanes walk the group's D channels in coalesced runs.  Taps are
+// accumulated in the reference's order (kernel_w outer, kernel_h inner; dcnv3_im2col_cuda.cuh:248-276) in opmath A.
+// More than 64 taps (kernels above 8x8) go through the owner lanes in chunks of 64; D > 64 walks channel chunks.
 template <typename T, typename A>
 __global__ __launch_bounds__(256) void dcnv3_any_fwd_kernel(const AnyKP p) {
-    const long index = (long)blockIdx.x * 256 + threadIdx.x;
-    if (index >= p.rows * p.G * p.D) return;
-    long t = index;
-    const int c = (int)(t % p.D); t /= p.D;
-    const long sampling_index = t;
-    const int g = (int)(t % p.G); t /= p.G;
-    const int p0_w = ((p.dw * (p.kw - 1)) >> 1) - p.pw + (int)(t % p.Wo) * p.sw; t /= p.Wo;
-    const int p0_h = ((p.dh * (p.kh - 1)) >> 1) - p.ph + (int)(t % p.Ho) * p.sh; t /= p.Ho;
-    const int b = (int)t;
-    const int P = p.kh * p.kw - p.rc;
-    long wptr = sampling_index * P, lptr = wptr << 1;
-    const T* off = reinterpret_cast<const T*>(p.off);
-    const T* msk = reinterpret_cast<const T*>(p.mask);
-    const int w_stride = p.G * p.D, h_stride = p.W * w_stride, base = g * p.D + c;
-    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * h_stride;
+    const long wid = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wid >= p.rows * p.G) return;                                   // wave-uniform
+    const int g = (int)(wid % p.G);
+    const long pix = wid / p.G;
+    const int wo = (int)(pix % p.Wo), ho = (int)((pix / p.Wo) % p.Ho), b = (int)(pix / ((long)p.Wo * p.Ho));
+    const int P = p.kh * p.kw - p.rc, centre = (p.kw / 2) * p.kh + p.kh / 2;
     const A os = (A)p.os;
-    const A p0_w_ = (A)p0_w - (A)((p.dw * (p.kw - 1)) >> 1) * os;
-    const A p0_h_ = (A)p0_h - (A)((p.dh * (p.kh - 1)) >> 1) * os;
-    A col = 0;
-    for (int i = 0; i < p.kw; ++i)
-        for (int j = 0; j < p.kh; ++j) {
-            if (p.rc && i == p.kw / 2 && j == p.kh / 2) continue;
-            const A loc_w = p0_w_ + ((A)(i * p.dw) + (A)off[lptr]) * os;
-            const A loc_h = p0_h_ + ((A)(j * p.dh) + (A)off[lptr + 1]) * os;
-            const A weight = (A)msk[wptr];
-            if (loc_h > (A)-1 && loc_w > (A)-1 && loc_h < (A)p.H && loc_w < (A)p.W) {
-                const int h_low = (int)floor(loc_h), w_low = (int)floor(loc_w), h_high = h_low + 1, w_high = w_low + 1;
-                const A lh = loc_h - (A)h_low, lw = loc_w - (A)w_low, hh = (A)1 - lh, hw = (A)1 - lw;
-                A v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-                if (h_low >= 0 && w_low >= 0) v1 = (A)im[h_low * h_stride + w_low * w_stride + base];
-                if (h_low >= 0 && w_high <= p.W - 1) v2 = (A)im[h_low * h_stride + w_high * w_stride + base];
-                if (h_high <= p.H - 1 && w_low >= 0) v3 = (A)im[h_high * h_stride + w_low * w_stride + base];
-                if (h_high <= p.H - 1 && w_high <= p.W - 1) v4 = (A)im[h_high * h_stride + w_high * w_stride + base];
-                col += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * weight;
+    // dcnv3_im2col_cuda.cuh:236-244: p0 = centre of the undeformed window, p0_ = p0 - half window * offset_scale
+    const int hw_ = (p.dw * (p.kw - 1)) >> 1, hh_ = (p.dh * (p.kh - 1)) >> 1;
+    const A p0_w_ = (A)(hw_ - p.pw + wo * p.sw) - (A)hw_ * os;
+    const A p0_h_ = (A)(hh_ - p.ph + ho * p.sh) - (A)hh_ * os;
+    const long cs = (long)p.G * p.D;
+    const T* off = reinterpret_cast<const T*>(p.off) + wid * P * 2;      // flat buffers, consumed row by row (:226-234)
+    const T* msk = reinterpret_cast<const T*>(p.mask) + wid * P;
+    const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * cs + (long)g * p.D;
+    T* out = reinterpret_cast<T*>(p.out) + wid * p.D;
+    A w1 = 0, w2 = 0, w3 = 0, w4 = 0, mw = 0;     // lane t: tap (q0 + t)
+    long o11 = 0;
+    int ex = 0, ey = 0;
+    auto own_tap = [&](int q0) {
+        const int q = q0 + lane;
+        w1 = w2 = w3 = w4 = mw = 0;
+        o11 = 0; ex = ey = 0;
+        if (q < P) {
+            const int qq = (p.rc && q >= centre) ? q + 1 : q;          // window position of tap q when the centre is removed
+            const int i = qq / p.kh, j = qq - i * p.kh;
+            const A lw_ = p0_w_ + ((A)(i * p.dw) + (A)off[2 * q]) * os;
+            const A lh_ = p0_h_ + ((A)(j * p.dh) + (A)off[2 * q + 1]) * os;
+            if (lh_ > (A)-1 && lw_ > (A)-1 && lh_ < (A)p.H && lw_ < (A)p.W) {
+                const A fh = floor(lh_), fw = floor(lw_);
+                const int y0 = (int)fh, x0 = (int)fw, y1 = y0 + 1, x1 = x0 + 1;
+                const A lh = lh_ - fh, lw = lw_ - fw, hh = (A)1 - lh, hw = (A)1 - lw;
+                const bool t = y0 >= 0, bo = y1 <= p.H - 1, l = x0 >= 0, r = x1 <= p.W - 1;
+                w1 = (t && l) ? hh * hw : (A)0;
+                w2 = (t && r) ? hh * lw : (A)0;
+                w3 = (bo && l) ? lh * hw : (A)0;
+                w4 = (bo && r) ? lh * lw : (A)0;
+                const int cy0 = max(y0, 0), cy1 = min(y1, p.H - 1), cx0 = max(x0, 0), cx1 = min(x1, p.W - 1);
+                o11 = ((long)cy0 * p.W + cx0) * cs;
+                ex = (int)((cx1 - cx0) * cs);
+                ey = (int)((long)(cy1 - cy0) * p.W * cs);
+                mw = (A)msk[q];
             }
-            wptr += 1; lptr += 2;
         }
-    reinterpret_cast<T*>(p.out)[index] = (T)col;
+    };
+    for (int c0 = 0; c0 < p.D; c0 += 64) {
+        const int c = c0 + lane;
+        A col = 0;
+        for (int q0 = 0; q0 < P; q0 += 64) {
+            if (c0 == 0 || P > 64) own_tap(q0);
+            const int n = min(64, P - q0);
+            for (int s = 0; s < n; ++s) {
+                const A a1 = __shfl(w1, s, 64), a2 = __shfl(w2, s, 64), a3 = __shfl(w3, s, 64), a4 = __shfl(w4, s, 64);
+                const A wg = __shfl(mw, s, 64);
+                const long o = __shfl(o11, s, 64);
+                const int dx = __shfl(ex, s, 64), dy = __shfl(ey, s, 64);
+                if (c < p.D) {
+                    const T* q = im + o + c;
+                    const A v1 = (A)q[0], v2 = (A)q[dx], v3 = (A)q[dy], v4 = (A)q[dx + dy];
+                    col += (a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4) * wg;
+                }
+            }
+        }
+        if (c < p.D) out[c] = (T)col;
+    }
 }
 
 template <typename A> __device__ __forceinline__ A wave_sum(A v) {
@@ -158,11 +195,12 @@ extern "C" int gp_dcnv3_forward_any(const void* in, const void* offset, const vo
     if (rc != GP_OK) return rc;
     p.in = in; p.off = offset; p.mask = mask; p.out = out; p.os = (double)offset_scale;
     hipStream_t s = (hipStream_t)stream;
-    const long total = p.rows * G * D;
+    const long total = p.rows * G * D, waves = p.rows * G;
     const int P = kh * kw - p.rc, esz = dtype == GP_F16 ? 2 : dtype == GP_F32 ? 4 : 8;
     gp_timing_before(s, GP_KC_DCNV3, (double)total * P * 8.0, ((double)N * H * W * G * D + (double)p.rows * G * P * 3 + (double)total) * esz);
     gp_timing_label("dcnv3_any fwd N%d %dx%d k%dx%d G%d D%d dt%d", N, H, W, kh, kw, G, D, dtype);
-    const dim3 grid((unsigned)cdiv(total, 256));
+    GP_REQUIRE(cdiv(waves * 64, 256) < (1l << 31), "gp_dcnv3_forward_any: grid too large");
+    const dim3 grid((unsigned)cdiv(waves * 64, 256));
     if (dtype == GP_F16) hipLaunchKernelGGL((dcnv3_any_fwd_kernel<half_t, float>), grid, dim3(256), 0, s, p);
     else if (dtype == GP_F32) hipLaunchKernelGGL((dcnv3_any_fwd_kernel<float, float>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((dcnv3_any_fwd_kernel<double, double>), grid, dim3(256), 0, s, p);
