@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
+ABI_VERSION = 300        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
 GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
@@ -27,7 +28,8 @@ class GemmDesc(Structure):
                 ("stride", c_int), ("pad", c_int), ("Ho", c_int), ("Wo", c_int), ("dtype", c_int),
                 ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int),
                 ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
-                ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long)]
+                ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long),
+                ("split_shift", c_int), ("x_plane_stride", c_long), ("w_plane_stride", c_long)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)
@@ -40,6 +42,7 @@ PROTOTYPES = {
     "gp_dcnv3_forward_any": ([_P] * 4 + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_dcnv3_backward": ([_P] * 7 + [c_long, c_long] + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_gemm": ([POINTER(GemmDesc), _P], c_int),
+    "gp_split_planes": ([_P, _P, c_long, c_int, c_long, c_long, c_int, _P], c_int),
     "gp_convnext_mlp_pack_w2": ([_P, _P, c_int, _P], c_int),
     "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
@@ -102,6 +105,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = restype
+    if lib.gp_version() != ABI_VERSION:      # a stale build would read gp_gemm_desc with another layout
+        raise GivePoseHipError(f"{LIB_PATH}: ABI version {lib.gp_version()}, this package needs {ABI_VERSION}: rebuild with "
+                               "`python -m givepose_amd.build`")
     _lib = lib
     return lib
 

@@ -199,8 +199,9 @@ extern "C" int gp_dcnv3_forward_any(const void* in, const void* offset, const vo
     const int P = kh * kw - p.rc, esz = dtype == GP_F16 ? 2 : dtype == GP_F32 ? 4 : 8;
     gp_timing_before(s, GP_KC_DCNV3, (double)total * P * 8.0, ((double)N * H * W * G * D + (double)p.rows * G * P * 3 + (double)total) * esz);
     gp_timing_label("dcnv3_any fwd N%d %dx%d k%dx%d G%d D%d dt%d", N, H, W, kh, kw, G, D, dtype);
-    GP_REQUIRE(cdiv(waves * 64, 256) < (1l << 31), "gp_dcnv3_forward_any: grid too large");
-    const dim3 grid((unsigned)cdiv(waves * 64, 256));
+    const long nblk = (waves + 3) / 4;   // four wavefronts per workgroup
+    GP_REQUIRE(nblk < (1l << 31), "gp_dcnv3_forward_any: grid too large");
+    const dim3 grid((unsigned)nblk);
     if (dtype == GP_F16) hipLaunchKernelGGL((dcnv3_any_fwd_kernel<half_t, float>), grid, dim3(256), 0, s, p);
     else if (dtype == GP_F32) hipLaunchKernelGGL((dcnv3_any_fwd_kernel<float, float>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((dcnv3_any_fwd_kernel<double, double>), grid, dim3(256), 0, s, p);

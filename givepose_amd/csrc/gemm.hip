@@ -40,6 +40,13 @@ struct GemmKP {
     int dbg;  // timing-only ablations of the large-tile kernel: 1 = no in-loop DMA, 2 = no MFMA/LDS reads (wrong results)
     const char* pf;   // gp_gemm_desc.prefetch: bytes [0, pf_bytes) touched by the workgroups as they start (hint)
     long pf_bytes;
+    // split-operand mode (gp_gemm_desc.split_shift > 0): X and W are fp16 PLANES, hi at the pointer and lo' = fp16((v - hi) * 2^S)
+    // xplane_b / wplane_b bytes behind it; the K loop runs three segments of split_n1 steps each -- X_hi W_lo', X_lo' W_hi,
+    // then (accumulators scaled by split_scale = 2^-S) X_hi W_hi -- so every fp16 schedule of this file computes
+    // x w = x_hi w_hi + 2^-S (x_hi w_lo' + x_lo' w_hi) to ~2^-22 relative with fp32 accumulation.  Output and residual are fp32.
+    int split_n1;
+    long xplane_b, wplane_b;
+    float split_scale;
 };
 
 template <typename T>
@@ -349,9 +356,11 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
                  : "memory");
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false>
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP pin) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
+    static_assert(!SPL || sizeof(T) == 2, "split-operand mode: fp16 planes");
+    typedef typename std::conditional<SPL, float, T>::type RT;   // residual / output element (SPL: always fp32)
     // split-K (generic ring schedule only): workgroup row blockIdx.y multiplies K steps [kt0, kt0 + nkt) into its own
     // fp32 slab of the workspace; the host passes C = workspace, out_f32, no bias / epilogue (splitk_reduce_kernel applies them)
     GemmKP p = pin;
@@ -437,6 +446,13 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         long xoff;      // wave-uniform byte offset of this K step from the row base pointer
         unsigned bit = 1u;
         kt += kt0;
+        long xadd = 0, wadd = 0;
+        if constexpr (SPL) {   // segment of the concatenated K: 0 = X_hi W_lo', 1 = X_lo' W_hi, 2 = X_hi W_hi
+            const int seg = (kt >= p.split_n1 ? 1 : 0) + (kt >= 2 * p.split_n1 ? 1 : 0);
+            kt -= seg * p.split_n1;
+            xadd = seg == 1 ? p.xplane_b : 0;
+            wadd = seg == 0 ? p.wplane_b : 0;
+        }
         if (p.conv) {
             const int tap = kt / cpt;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -447,15 +463,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         }
         const char* zp = reinterpret_cast<const char*>(zero);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) glds16((xmask[i] & bit) ? xptr[i] + xoff : zp, xs + i * NW * 1024);
+        for (int i = 0; i < XI; ++i) glds16((xmask[i] & bit) ? xptr[i] + xoff + xadd : zp, xs + i * NW * 1024);
 #pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * RB : zp, ws + i * NW * 1024);
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] ? wptr[i] + (long)kt * RB + wadd : zp, ws + i * NW * 1024);
     };
 
     // the lean epilogue (fp16 output, tile fully inside C: see epilogue_lean) takes the bias as the initial value of
     // the accumulators: in the MFMA register layout it is 4 registers per n-tile, and the add leaves the epilogue
     bool lean = false;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && !SPL) {
         const bool res_epi = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
         lean = !p.out_f32 && p.dbg != 5 && m0 + BM <= p.M && n0 + BN <= p.N && p.ldc % 8 == 0 &&
                ((size_t)p.C & 15) == 0 && !(res_epi && (p.gn_partial || p.ldres % 8 || ((size_t)p.res & 15)));
@@ -468,6 +484,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
+    // split-operand mode: the cross terms (segments 0, 1) are accumulated first and scaled by 2^-S once, exactly, when the
+    // hi x hi segment begins (a K range of a split-K launch that ends before that point scales after its loop)
+    auto split_rescale = [&](int kt) {
+        if constexpr (SPL) {
+            if (kt + kt0 == 2 * p.split_n1) {
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] *= p.split_scale;
+            }
+        }
+    };
 
     const int fr = lane & 15, fq = lane >> 4, sw = fr & 7;
     const int xfo = (wm * MT * 16 + fr) * RB, wfo = (wn * NT * 16 + fr) * RB;
@@ -560,8 +588,15 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         auto stage_s = [&](int buf, int kt) {
             const unsigned xs = lds0 + buf * STAGE + wave * 1024;
             const unsigned ws = xs + BM * RB;
-            const char* bx = xtile + (long)kt * RB;
-            const char* bw = wtile + (long)kt * RB;
+            long xadd = 0, wadd = 0;
+            if constexpr (SPL) {
+                const int seg = (kt >= p.split_n1 ? 1 : 0) + (kt >= 2 * p.split_n1 ? 1 : 0);
+                kt -= seg * p.split_n1;
+                xadd = seg == 1 ? p.xplane_b : 0;
+                wadd = seg == 0 ? p.wplane_b : 0;
+            }
+            const char* bx = xtile + (long)kt * RB + xadd;
+            const char* bw = wtile + (long)kt * RB + wadd;
 #pragma unroll
             for (int i = 0; i < XI; ++i) glds16_s(bx, xo[i], xs + i * NW * 1024);
 #pragma unroll
@@ -602,6 +637,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             __builtin_amdgcn_s_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            split_rescale(kt);
             __builtin_amdgcn_s_setprio(1);
             if (p.dbg != 2) {
 #pragma unroll
@@ -648,6 +684,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         if (p.nkt > 1) stage(1, 1);
         for (int kt = 0; kt < p.nkt; ++kt) {
             const int buf = kt & 1;
+            split_rescale(kt);
             rd(buf, co1, xf1, wf1);
             __builtin_amdgcn_sched_barrier(0);
             mm(xf0, wf0);
@@ -676,6 +713,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     for (int kt = 0; kt < p.nkt; ++kt) {
         const bool more = kt + NS - 1 < p.nkt;
         if (more && p.dbg != 1) stage(nbuf, kt + NS - 1);
+        split_rescale(kt);
         if (p.dbg != 2) compute(buf);
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G * (NS - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -685,6 +723,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     }
     }
 
+    if constexpr (SPL) {
+        if (kt0 + p.nkt <= 2 * p.split_n1) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] *= p.split_scale;
+        }
+    }
     if (p.dbg == 3) {   // timing ablation: no epilogue (keeps the accumulators alive, stores nothing in practice)
         float s = 0.f;
 #pragma unroll
@@ -722,8 +768,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
     const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
     const bool sres = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
     const f32x4 g4 = (p.epi == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
-    constexpr bool PRE = sizeof(T) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
-    typename Res4<T>::type r4[PRE ? MT / 2 : 1][8];
+    constexpr bool PRE = sizeof(RT) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
+    typename Res4<RT>::type r4[PRE ? MT / 2 : 1][8];
     if (PRE) {
 #pragma unroll
         for (int j = 0; j < MT / 2; ++j)
@@ -731,7 +777,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             for (int i = 0; i < 8; ++i) {
                 const int m = mb + j * 32 + i * 4 + er;
                 for (int e = 0; e < 4; ++e) r4[PRE ? j : 0][i][e] = 0;
-                if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<T>(p, m, en);
+                if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<RT>(p, m, en);
             }
     }
     float gsum = 0.f, gsq = 0.f;
@@ -751,7 +797,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 for (int i = i0; i < i0 + 4; ++i) {
                     const int m = mb + j * 32 + i * 4 + er;
                     for (int e = 0; e < 4; ++e) r4[0][i][e] = 0;
-                    if (sres && nok && m < p.M) r4[0][i] = load_res4<T>(p, m, en);
+                    if (sres && nok && m < p.M) r4[0][i] = load_res4<RT>(p, m, en);
                 }
             }
 #pragma unroll
@@ -760,8 +806,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
                 const int m = mb + j * 32 + row;
                 if (m < p.M && nok) {
-                    const f32x4 o = epi_apply<T>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
-                    if (p.dbg != 4 || o[0] == 12345.678f) store4<T>(p, m, en, o);
+                    const f32x4 o = epi_apply<RT>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
+                    if (p.dbg != 4 || o[0] == 12345.678f) store4<RT>(p, m, en, o);
                     gsum += (o[0] + o[1]) + (o[2] + o[3]);
                     gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
                 }
@@ -1215,9 +1261,10 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     stores(T - 1);
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false> void launch_big(GemmKP& p, hipStream_t s) {
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
+    if constexpr (SPL) { p.split_n1 = p.nkt; p.nkt *= 3; }   // three K segments (GemmKP::split_n1)
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
     int splits = 1;
@@ -1229,7 +1276,7 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
             splits = p.splitk;
         }
     }
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP, SPL>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -1306,6 +1353,16 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     p.epi = d->epilogue; p.out_f32 = d->out_f32;
     p.ln_stats = d->ln_stats; p.ln_s = d->ln_colsum; p.ln_nsl = d->ln_nslab; p.ln_eps = d->ln_eps;
     if (d->prefetch && d->prefetch_bytes > 0 && prefetch_enabled()) { p.pf = reinterpret_cast<const char*>(d->prefetch); p.pf_bytes = d->prefetch_bytes; }
+    const bool split = d->split_shift > 0;
+    if (split) {   // split-operand mode: fp16 hi / lo' planes in, fp32 out (GemmKP::split_n1)
+        GP_REQUIRE(d->dtype == GP_F16 && d->out_f32, "gp_gemm: split-operand mode takes fp16 planes (dtype GP_F16) and writes fp32 (out_f32)");
+        GP_REQUIRE(d->split_shift <= 14 && d->x_plane_stride > 0 && d->w_plane_stride >= (long)d->N * d->K,
+                   "gp_gemm: split-operand mode needs split_shift <= 14 and the plane strides");
+        GP_REQUIRE(d->epilogue != GP_EPI_LNFOLD_GELU, "gp_gemm: split-operand mode has no LNFOLD epilogue");
+        GP_REQUIRE(d->x_plane_stride % 8 == 0 && d->w_plane_stride % 8 == 0, "gp_gemm: plane strides must keep 16-byte alignment");
+        p.xplane_b = d->x_plane_stride * 2; p.wplane_b = d->w_plane_stride * 2;
+        p.split_scale = ldexpf(1.0f, -d->split_shift);
+    }
     if (d->gn_partial) {
         GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
                    "gp_gemm: fused GroupNorm needs 4 or 8 channels per group");
@@ -1327,7 +1384,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(d->ldx >= d->K && d->ldx % (16 / esz) == 0, "gp_gemm: ldx=%d invalid", d->ldx);
     }
     p.splitk = d->splitk > 1 ? d->splitk : 1;
-    if (p.splitk > d->K / KPT) p.splitk = d->K / KPT;
+    if (p.splitk > d->K / KPT * (split ? 3 : 1)) p.splitk = d->K / KPT * (split ? 3 : 1);
     if (p.splitk > 1) GP_REQUIRE(d->workspace != nullptr, "gp_gemm: splitk needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * d->M * d->N * d->K;
@@ -1357,7 +1414,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // K = 512, >= 12288 rows, >= 1024 columns (stage-2 fc1 at bs 64): weights in registers (48.5 us against 51.4 for
             // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py); shorter M does not amortise the
             // 256 KB weight prologue per CU.  GP_GEMM_WREG=0: A/B switch
-            if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
+            if (wreg_ok && !split && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
             else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
@@ -1371,8 +1428,9 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
     GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
-    if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "");
-    else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "");
+    GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 (got %d)", variant);
+    if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
+    else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 16) {
         GP_REQUIRE(wreg_ok, "gp_gemm: variant 16 needs a plain fp16 GEMM with K = 512, N %% 256 == 0, M %% 32 == 0, epilogue none/gelu/relu/lrelu");
         const int nsl = d->N / 256, tiles = d->M / 32;
@@ -1409,7 +1467,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 10) {   // 256x256 ping-pong: 8 waves of 128x64, 64-byte K steps, 4-stage ring, one workgroup per CU
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        if (split) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true, true>(p, s);
+        else if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 11) {   // 128x256 ping-pong: 8 waves of 64x64
@@ -1418,7 +1477,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     }
     if (variant == 8) {   // 256x128, 4 waves of 128x64, 64-byte K steps, 3-stage ring: two workgroups per CU, so the
                           // epilogue of one overlaps the main loop of the other (short-K, store-heavy shapes)
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        if (split) launch_big<half_t, 2, 2, 8, 4, 3, false, 64, false, true>(p, s);
+        else if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 8, 4, 3, false, 64>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 9) {   // 128x128, 64-byte K steps, 4-stage ring, two workgroups per CU
@@ -1426,7 +1486,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 7) {
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        if (split) launch_big<half_t, 2, 2, 4, 4, 2, true, 128, false, true>(p, s);
+        else if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 5) {
@@ -1438,14 +1499,16 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // main kernel: raw fp32 partial sums, slab blockIdx.y of the workspace; then the reduce kernel with the real epilogue
             GemmKP q = p;
             q.C = d->workspace; q.out_f32 = 1; q.ldc = d->N; q.epi = GP_EPI_NONE; q.bias = nullptr; q.gamma = nullptr; q.res = nullptr;
-            if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(q, s); else launch_big<float, 2, 2, 4, 4, 2>(q, s);
+            if (split) launch_big<half_t, 2, 2, 4, 4, 2, false, 128, false, true>(q, s);
+            else if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(q, s); else launch_big<float, 2, 2, 4, 4, 2>(q, s);
             p.splitk = q.splitk;      // >= 2: the request was clamped to the number of K steps above
             const long work = (long)d->M * (d->N / 4);
-            if (d->dtype == GP_F16) hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
+            if (d->dtype == GP_F16 && !split) hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(cdiv(work, 256)), dim3(256), 0, s, p);   // (split mode: fp32 residual / output)
             GP_LAUNCH_CHECK("gp_gemm");
         }
-        if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
+        if (split) launch_big<half_t, 2, 2, 4, 4, 2, false, 128, false, true>(p, s);
+        else if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 3) {

@@ -1071,3 +1071,47 @@ extern "C" int gp_mask_resize_nearest(const float* mask, float* out, int B, int 
     hipLaunchKernelGGL(mask_resize_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, mask, out, B, S, R);
     GP_LAUNCH_CHECK("gp_mask_resize_nearest");
 }
+
+// =====================================================================================================
+// fp32 rows -> the hi / lo' fp16 planes of the split-operand GEMM mode (gp_gemm_desc.split_shift): hi = fp16(x),
+// lo' = fp16((x - hi) * 2^S).  x - hi is exact in fp32 (hi has 11 of x's leading bits), the scale is a power of two, so
+// the only roundings are the two conversions: x = hi + 2^-S lo' to 2^-22 relative down to |x| ~ 2^-(14+S).
+// 8 elements per lane: two 16-byte loads, one 16-byte store per plane.
+namespace {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, half_t* __restrict__ hi, half_t* __restrict__ lo,
+                                                           long rows, int cols8, long ldx, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const long r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    const float* src = x + r * ldx + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? a[j] : b[j - 4];
+        const half_t hv = (half_t)v;
+        h[j] = hv;
+        l[j] = (half_t)((v - (float)hv) * scale);
+    }
+    *reinterpret_cast<half8*>(hi + i * 8) = h;
+    *reinterpret_cast<half8*>(lo + i * 8) = l;
+}
+}  // namespace
+
+extern "C" int gp_split_planes(const float* x, void* planes, long rows, int cols, long ldx, long plane_stride, int split_shift,
+                               void* stream) {
+    GP_REQUIRE(x && planes, "gp_split_planes: null pointer");
+    GP_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldx >= cols && ldx % 4 == 0, "gp_split_planes: bad shape rows=%ld cols=%d ldx=%ld", rows, cols, ldx);
+    GP_REQUIRE(plane_stride >= rows * cols && plane_stride % 8 == 0, "gp_split_planes: plane_stride too small / unaligned");
+    GP_REQUIRE(split_shift > 0 && split_shift <= 14, "gp_split_planes: split_shift in 1..14");
+    GP_REQUIRE(((size_t)x & 15) == 0 && ((size_t)planes & 15) == 0, "gp_split_planes: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    const long total = rows * (cols / 8);
+    gp_timing_before(s, GP_KC_ELEMENTWISE, 0.0, (double)rows * cols * 8.0);
+    gp_timing_label("split_planes %ldx%d", rows, cols);
+    half_t* hi = reinterpret_cast<half_t*>(planes);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, hi, hi + plane_stride, rows, cols / 8, ldx,
+                       ldexpf(1.0f, split_shift));
+    GP_LAUNCH_CHECK("gp_split_planes");
+}

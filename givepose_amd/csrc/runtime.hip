@@ -19,7 +19,7 @@ int gp_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* gp_last_error(void) { return gp_err_buf; }
-extern "C" int gp_version(void) { return 100; }
+extern "C" int gp_version(void) { return GP_ABI_VERSION; }
 
 extern "C" int gp_device_info(int* cu_count, char* arch, int arch_len) {
     int dev = 0;

@@ -74,6 +74,65 @@ def _workspace(device, nfloats):
     return ws
 
 
+# ----------------------------------------------------------------------------------- split-operand mode
+SPLIT_SHIFT = 11        # lo' = fp16((v - fp16(v)) * 2^11): the low plane of a value sits in fp16's normal range whenever the high one does
+
+
+class SplitW:
+    """GEMM weights as the two fp16 planes of the split-operand mode (include/givepose_hip.h, gp_gemm_desc.split_shift):
+    ``planes`` (2, N, K) fp16 = [hi, lo'], made once on the host from the fp32 checkpoint tensor."""
+
+    def __init__(self, planes, shift=SPLIT_SHIFT):
+        self.planes, self.shift = planes, shift
+        self.shape = tuple(planes.shape[1:])
+        self.dtype, self.device = torch.float32, planes.device     # what the layer computes in / where
+
+    def numel(self):
+        return self.planes.numel()
+
+    def element_size(self):
+        return 2
+
+    def data_ptr(self):
+        return self.planes.data_ptr()
+
+
+def split_weights(w, device, shift=SPLIT_SHIFT):
+    """fp32 (N, K) host tensor -> SplitW on `device` (host arithmetic: exact subtraction, power-of-two scale)."""
+    w = w.detach().to(device="cpu", dtype=torch.float32).contiguous()
+    hi = w.half()
+    lo = ((w - hi.float()) * float(2 ** shift)).half()
+    return SplitW(torch.stack([hi, lo], 0).contiguous().to(device), shift)
+
+
+_SPLIT_WS = {}
+_SPLIT_WS_RETIRED = []
+
+
+def _split_scratch(device, nhalfs):
+    """Per-stream scratch for the X planes of a split-operand GEMM (same lifetime rules as the split-K workspace)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLIT_WS.get(key)
+    if ws is None or ws.numel() < nhalfs:
+        if _lib.capturing():
+            raise RuntimeError("split-plane scratch allocation during hipGraph capture (run the same shapes eagerly once first)")
+        if ws is not None:
+            _SPLIT_WS_RETIRED.append(ws)
+        ws = torch.empty(max(nhalfs, 1 << 22), dtype=torch.float16, device=device)
+        _SPLIT_WS[key] = ws
+    return ws
+
+
+def split_planes(x, rows, cols, ldx, out=None, shift=SPLIT_SHIFT):
+    """fp32 (rows, cols) with row stride ldx -> fp16 planes [hi | lo'] (2, rows, cols) in `out` (default: the stream's scratch)."""
+    _chk(x, "x", torch.float32)
+    n = rows * cols
+    if out is None:
+        out = _split_scratch(x.device, 2 * n)
+    check(_L().gp_split_planes(_ptr(x), _ptr(out), rows, cols, ldx, n, shift, _stream()), "gp_split_planes")
+    return out
+
+
 # Automatic split-K for skinny GEMMs (the PnP fc layers, feat_reducer): 128x128 LDS-DMA tiles + a reduce kernel.
 # (Round 1 ran split-K on a register-staged kernel whose MFMA loop corrupted packed-fp32 results of OTHER kernels' waves
 # on the same SIMD when batches overlapped -- that kernel is gone, DESIGN.md 6b.)
@@ -98,9 +157,17 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM.
     prefetch = a tensor (the weights of the NEXT launch on this stream) to be pulled towards the caches meanwhile: a hint."""
+    split = isinstance(w, SplitW)
     dt = x.dtype
-    code = dtype_code(dt)
-    _chk(x, "x"), _chk(w, "w", dt), _chk(out, "out")
+    if split:
+        # fp32 activations in, fp32 out; the MFMA operands are fp16 hi / lo' planes (X split here, W by the host)
+        _chk(x, "x", torch.float32), _chk(out, "out", torch.float32)
+        if residual is not None:
+            _chk(residual, "residual", torch.float32)
+        code = GP_F16
+    else:
+        code = dtype_code(dt)
+        _chk(x, "x"), _chk(w, "w", dt), _chk(out, "out")
     N = w.shape[0]
     Kw = w.shape[1]
     d = GemmDesc()
@@ -117,14 +184,27 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
         K = Kw if K is None else K
         ldx = x.stride(0) if ldx is None else ldx
     assert K == Kw, (K, Kw)
-    out_f32 = 1 if (out.dtype == torch.float32 and dt != torch.float32) else 0
-    if out.dtype not in (dt, torch.float32):
-        raise TypeError("gemm: out dtype must equal x dtype or float32")
+    xptr = x.data_ptr()
+    if split:
+        if conv is not None:
+            if not x.is_contiguous():
+                raise RuntimeError("gemm(split, conv): x must be contiguous")
+            rows, cols, ld = x.numel() // conv["Cin"], conv["Cin"], conv["Cin"]
+        else:
+            rows, cols, ld = M, K, ldx
+            ldx = K                      # the planes are dense
+        xptr = split_planes(x, rows, cols, ld, shift=w.shift).data_ptr()
+        d.split_shift, d.x_plane_stride, d.w_plane_stride = w.shift, rows * cols, N * K
+        out_f32 = 1
+    else:
+        out_f32 = 1 if (out.dtype == torch.float32 and dt != torch.float32) else 0
+        if out.dtype not in (dt, torch.float32):
+            raise TypeError("gemm: out dtype must equal x dtype or float32")
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
     if splitk is None:
         splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 4) and gn is None and ln is None) else 1
-    d.X, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.X, d.W, d.C = xptr, w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None
     d.residual = residual.data_ptr() if residual is not None else None

@@ -44,8 +44,16 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 
 class PoseNet(nn.Module):
-    def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None, inflight=1):
+    def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None, inflight=1,
+                 split_gemm=False):
+        """dtype: storage type of activations / weights (float16 = throughput mode, float32 = parity mode).
+        split_gemm (float32 only): the dense contractions run on the fp16 matrix pipe with split operands (hi + 2^-11 lo'
+        planes, three MFMAs per product, fp32 accumulate: gp_gemm_desc.split_shift) instead of the fp32 MFMA; everything
+        else is the float32 mode.  Error against the reference at the level of the fp32 mode (tests/precision_split.py)."""
         super().__init__()
+        if split_gemm and dtype != torch.float32:
+            raise ValueError("split_gemm is a float32-storage mode")
+        self.split_gemm = bool(split_gemm)
         # the reference asserts backbone == 'convnext' (network/PoseNet.py:142); 'resnet34' (network/resnet.py:167-176,
         # defined but never wired there) is this build's throughput variant with feature_channel 512
         if cfg.main_backbone not in ("convnext", "resnet34"):
@@ -117,6 +125,8 @@ class PoseNet(nn.Module):
         T = self.compute_dtype
         f32 = lambda t: t.contiguous().float().to(device)
         lowp = lambda t: t.contiguous().to(T).to(device)
+        # operands of gp_gemm: storage type, or hi / lo' fp16 planes in the split-operand mode
+        gw = (lambda t: ops.split_weights(t.reshape(t.shape[0], -1), device)) if self.split_gemm else lowp
         W = {}
         cfg = self.cfg
         g = lambda k: sd["backbone." + k]
@@ -131,10 +141,10 @@ class PoseNet(nn.Module):
                     p, q = f"layer{li}.{bi}", f"rs{li}.{bi}."
                     for c in ("1", "2"):
                         w, b = fold(p + ".conv" + c, p + ".bn" + c)
-                        W[q + "w" + c], W[q + "b" + c] = lowp(w.permute(0, 2, 3, 1).reshape(planes, -1)), f32(b)
+                        W[q + "w" + c], W[q + "b" + c] = gw(w.permute(0, 2, 3, 1).reshape(planes, -1)), f32(b)
                     if ("backbone." + p + ".downsample.0.weight") in sd:
                         w, b = fold(p + ".downsample.0", p + ".downsample.1")
-                        W[q + "wd"], W[q + "bd"] = lowp(w.reshape(planes, -1)), f32(b)
+                        W[q + "wd"], W[q + "bd"] = gw(w.reshape(planes, -1)), f32(b)
         for s, (d, n) in enumerate(zip(cfg.convnext_dims, cfg.convnext_depths) if cfg.main_backbone == "convnext" else ()):
             if s == 0:
                 W["stem.w"], W["stem.b"] = f32(g("stem_0.weight").reshape(-1, 48).t()), f32(g("stem_0.bias"))
@@ -142,15 +152,15 @@ class PoseNet(nn.Module):
             if s > 0:
                 p = f"stages_{s}.downsample."
                 W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"] = f32(g(p + "0.weight")), f32(g(p + "0.bias"))
-                W[f"ds{s}.w"] = lowp(g(p + "1.weight").permute(0, 2, 3, 1).reshape(d, -1))
+                W[f"ds{s}.w"] = gw(g(p + "1.weight").permute(0, 2, 3, 1).reshape(d, -1))
                 W[f"ds{s}.b"] = f32(g(p + "1.bias"))
             for b in range(n):
                 p, q = f"stages_{s}.blocks.{b}.", f"s{s}b{b}."
                 W[q + "dw_w"] = lowp(g(p + "conv_dw.weight").reshape(d, 49).t())
                 W[q + "dw_b"] = f32(g(p + "conv_dw.bias"))
                 W[q + "ln_w"], W[q + "ln_b"] = f32(g(p + "norm.weight")), f32(g(p + "norm.bias"))
-                W[q + "fc1_w"], W[q + "fc1_b"] = lowp(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
-                W[q + "fc2_w"], W[q + "fc2_b"] = lowp(g(p + "mlp.fc2.weight")), f32(g(p + "mlp.fc2.bias"))
+                W[q + "fc1_w"], W[q + "fc1_b"] = gw(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
+                W[q + "fc2_w"], W[q + "fc2_b"] = gw(g(p + "mlp.fc2.weight")), f32(g(p + "mlp.fc2.bias"))
                 W[q + "gamma"] = f32(g(p + "gamma"))
                 if T == torch.float16 and d in (128, 256) and cfg.fuse_mlp:   # fused fc1->GELU->fc2 (csrc/mlp.hip)
                     W[q + "fc2_wp"] = ops.convnext_mlp_pack_w2(W[q + "fc2_w"])
@@ -162,10 +172,10 @@ class PoseNet(nn.Module):
                     W[q + "fc1_cb"] = f32(w1 @ lb + g(p + "mlp.fc1.bias"))
         for head in ("xyz_nocs_head", "xyz_deform_head"):
             h = lambda k: sd[f"{head}.{k}"]
-            W[head + ".deconv_w"] = lowp(h("features.0.weight").permute(2, 3, 1, 0).reshape(9 * 256, -1))
+            W[head + ".deconv_w"] = gw(h("features.0.weight").permute(2, 3, 1, 0).reshape(9 * 256, -1))
             W[head + ".gn0_w"], W[head + ".gn0_b"] = f32(h("features.1.weight")), f32(h("features.1.bias"))
             for i in (3, 4, 6, 7, 9, 10):
-                W[f"{head}.c{i}_w"] = lowp(h(f"features.{i}.conv.weight").permute(0, 2, 3, 1).reshape(256, -1))
+                W[f"{head}.c{i}_w"] = gw(h(f"features.{i}.conv.weight").permute(0, 2, 3, 1).reshape(256, -1))
                 W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"] = f32(h(f"features.{i}.norm.weight")), f32(h(f"features.{i}.norm.bias"))
             W[head + ".out_w"], W[head + ".out_b"] = f32(h("out_layer.weight").reshape(3, 256)), f32(h("out_layer.bias"))
         # SizeHead: fold eval BatchNorm1d into conv1 (pose_head.py:34-35)
@@ -175,7 +185,7 @@ class PoseNet(nn.Module):
         W["size.w2"], W["size.b2"] = f32(sd["size_head.conv2.weight"].squeeze(-1)), f32(sd["size_head.conv2.bias"])
         if cfg.nocsmap_encoder == "att":      # MAPTransformerEncoer (network/attention_pnp_net.py:126-157)
             a = lambda k: sd["nocs_encoder." + k]
-            W["att.pe_w"] = lowp(a("patch_embed.proj.weight").permute(0, 2, 3, 1).reshape(256, -1))   # K = (ky,kx,c)
+            W["att.pe_w"] = gw(a("patch_embed.proj.weight").permute(0, 2, 3, 1).reshape(256, -1))   # K = (ky,kx,c)
             W["att.pe_b"] = f32(a("patch_embed.proj.bias"))
             W["att.pos"] = f32(a("pos_embed").reshape(64, 256))                                      # tiled per batch in _plan
             W["att.ones"] = torch.ones(256, dtype=torch.float32, device=device)
@@ -184,46 +194,46 @@ class PoseNet(nn.Module):
                 q = f"att{i}."
                 for n in ("norm1", "norm2"):
                     W[q + n + "_w"], W[q + n + "_b"] = f32(a(f"block.{i}.{n}.weight")), f32(a(f"block.{i}.{n}.bias"))
-                W[q + "qkv_w"] = lowp(a(f"block.{i}.attn.qkv.weight"))
-                W[q + "proj_w"], W[q + "proj_b"] = lowp(a(f"block.{i}.attn.proj.weight")), f32(a(f"block.{i}.attn.proj.bias"))
-                W[q + "fc1_w"], W[q + "fc1_b"] = lowp(a(f"block.{i}.mlp.fc1.weight")), f32(a(f"block.{i}.mlp.fc1.bias"))
-                W[q + "fc2_w"], W[q + "fc2_b"] = lowp(a(f"block.{i}.mlp.fc2.weight")), f32(a(f"block.{i}.mlp.fc2.bias"))
+                W[q + "qkv_w"] = gw(a(f"block.{i}.attn.qkv.weight"))
+                W[q + "proj_w"], W[q + "proj_b"] = gw(a(f"block.{i}.attn.proj.weight")), f32(a(f"block.{i}.attn.proj.bias"))
+                W[q + "fc1_w"], W[q + "fc1_b"] = gw(a(f"block.{i}.mlp.fc1.weight")), f32(a(f"block.{i}.mlp.fc1.bias"))
+                W[q + "fc2_w"], W[q + "fc2_b"] = gw(a(f"block.{i}.mlp.fc2.weight")), f32(a(f"block.{i}.mlp.fc2.bias"))
         for li, i in enumerate((0, 3, 6) if cfg.nocsmap_encoder == "conv" else ()):
             p, q = f"nocs_encoder.features.{i}.", f"enc{li}."
             if cfg.use_dcn == "dcnv3":
                 cw = sd[p + "conv.weight"].reshape(256, -1)
-                W[q + "conv_w"] = f32(cw) if li == 0 else lowp(cw)
+                W[q + "conv_w"] = f32(cw) if li == 0 else gw(cw)
                 W[q + "conv_b"] = f32(sd[p + "conv.bias"])
                 d = p + "dcnv3."
                 W[q + "dw_w"] = lowp(sd[d + "dw_conv.0.weight"].reshape(256, 9).t())
                 W[q + "dw_b"] = f32(sd[d + "dw_conv.0.bias"])
                 W[q + "ln_w"], W[q + "ln_b"] = f32(sd[d + "dw_conv.1.1.weight"]), f32(sd[d + "dw_conv.1.1.bias"])
-                W[q + "om_w"] = lowp(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
+                W[q + "om_w"] = gw(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
                 W[q + "om_b"] = f32(torch.cat([sd[d + "offset.bias"], sd[d + "mask.bias"]], 0))
-                W[q + "in_w"], W[q + "in_b"] = lowp(sd[d + "input_proj.weight"]), f32(sd[d + "input_proj.bias"])
+                W[q + "in_w"], W[q + "in_b"] = gw(sd[d + "input_proj.weight"]), f32(sd[d + "input_proj.bias"])
                 # input_proj(conv1x1(x)) is one linear map: fold the two (fp32 product, then storage rounding) so the
                 # full-resolution 256-channel `conv` output is only materialised for the prefix the dw_conv branch reads
                 wf = sd[d + "input_proj.weight"] @ cw
-                W[q + "fold_w"] = f32(wf) if li == 0 else lowp(wf)
+                W[q + "fold_w"] = f32(wf) if li == 0 else gw(wf)
                 W[q + "fold_b"] = f32(sd[d + "input_proj.weight"] @ sd[p + "conv.bias"] + sd[d + "input_proj.bias"])
-                W[q + "out_w"], W[q + "out_b"] = lowp(sd[d + "output_proj.weight"]), f32(sd[d + "output_proj.bias"])
+                W[q + "out_w"], W[q + "out_b"] = gw(sd[d + "output_proj.weight"]), f32(sd[d + "output_proj.bias"])
             else:
                 cw = sd[p + "weight"]
-                W[q + "conv_w"] = f32(cw.reshape(256, -1).t()) if li == 0 else lowp(cw.permute(0, 2, 3, 1).reshape(256, -1))
+                W[q + "conv_w"] = f32(cw.reshape(256, -1).t()) if li == 0 else gw(cw.permute(0, 2, 3, 1).reshape(256, -1))
             W[q + "gn_w"], W[q + "gn_b"] = f32(sd[f"nocs_encoder.features.{i + 1}.weight"]), f32(sd[f"nocs_encoder.features.{i + 1}.bias"])
-        W["red.w"], W["red.b"] = lowp(sd["feat_reducer.weight"].reshape(256, -1)), f32(sd["feat_reducer.bias"])
+        W["red.w"], W["red.b"] = gw(sd["feat_reducer.weight"].reshape(256, -1)), f32(sd["feat_reducer.bias"])
         W["pnp.c0_w"] = f32(sd["pnp_net.features.0.weight"].reshape(128, -1).t())
         for li, i in enumerate((0, 3, 6)):
             if li > 0:
-                W[f"pnp.c{li}_w"] = lowp(sd[f"pnp_net.features.{i}.weight"].permute(0, 2, 3, 1).reshape(128, -1))
+                W[f"pnp.c{li}_w"] = gw(sd[f"pnp_net.features.{i}.weight"].permute(0, 2, 3, 1).reshape(128, -1))
             W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"] = f32(sd[f"pnp_net.features.{i + 1}.weight"]), f32(sd[f"pnp_net.features.{i + 1}.bias"])
         # fc1 || fc1_z as one GEMM; columns permuted from the reference's NCHW flatten (c*64+hw,
         # conv_pnp_net.py:170-172) to the channels-last flatten (hw*128+c) used on the device
         perm = lambda w: w.reshape(-1, 128, 64).permute(0, 2, 1).reshape(-1, 8192)
-        W["pnp.fc1_w"] = lowp(torch.cat([perm(sd["pnp_net.fc1.weight"]), perm(sd["pnp_net.fc1_z.weight"])], 0))
+        W["pnp.fc1_w"] = gw(torch.cat([perm(sd["pnp_net.fc1.weight"]), perm(sd["pnp_net.fc1_z.weight"])], 0))
         W["pnp.fc1_b"] = f32(torch.cat([sd["pnp_net.fc1.bias"], sd["pnp_net.fc1_z.bias"]], 0))
-        W["pnp.fc2_w"], W["pnp.fc2_b"] = lowp(sd["pnp_net.fc2.weight"]), f32(sd["pnp_net.fc2.bias"])
-        W["pnp.fc2z_w"], W["pnp.fc2z_b"] = lowp(sd["pnp_net.fc2_z.weight"]), f32(sd["pnp_net.fc2_z.bias"])
+        W["pnp.fc2_w"], W["pnp.fc2_b"] = gw(sd["pnp_net.fc2.weight"]), f32(sd["pnp_net.fc2.bias"])
+        W["pnp.fc2z_w"], W["pnp.fc2z_b"] = gw(sd["pnp_net.fc2_z.weight"]), f32(sd["pnp_net.fc2_z.bias"])
         for n in ("fc_r", "fc_t", "fc_z"):
             W[n + ".w"], W[n + ".b"] = f32(sd[f"pnp_net.{n}.weight"]), f32(sd[f"pnp_net.{n}.bias"])
         self._packed = W

@@ -42,7 +42,8 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-int gp_version(void);
+#define GP_ABI_VERSION 300 /* round 3: gp_gemm_desc grew (split-operand fields); round 2 (prefetch fields) was 200 */
+int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
 
@@ -142,8 +143,21 @@ typedef struct gp_gemm_desc {
      * Honoured by every variant. */
     const void* prefetch;
     long prefetch_bytes;
+    /* split-operand mode (parity-grade results at the fp16 MFMA rate), split_shift = S > 0:
+     *   X and W point at fp16 PLANES: hi = fp16(v) at the pointer, lo' = fp16((v - hi) * 2^S) x_plane_stride / w_plane_stride
+     *   ELEMENTS behind it (gp_split_planes makes them; weights are split once by the host); the kernel accumulates
+     *   x_hi w_lo' + x_lo' w_hi, scales by 2^-S (exact) and adds x_hi w_hi, all in fp32: |error| ~ 2^-22 |x||w| per product,
+     *   i.e. what an fp32 GEMM's own accumulation rounding amounts to.  Requires dtype GP_F16, out_f32 != 0 (C fp32);
+     *   residual (if any) is fp32; ldx / Cin / K address one plane; variant 0 / 4 / 7 / 8 / 10. */
+    int split_shift;
+    long x_plane_stride, w_plane_stride;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
+
+/* fp32 rows -> the two fp16 planes of the split-operand mode: hi (rows, cols) at `planes`, lo' plane_stride elements behind
+ * it; x rows have stride ldx (elements), the planes are dense (row stride = cols).  cols % 8 == 0, x 16-byte aligned rows. */
+int gp_split_planes(const float* x, void* planes, long rows, int cols, long ldx, long plane_stride, int split_shift,
+                    void* stream);
 
 /* Fused ConvNeXt block MLP (fp16 storage, C = 128 or 256): one launch for
  *   out = residual + gamma * ( fc2( GELU( fc1(x) ) ) )
