@@ -29,7 +29,8 @@ class GemmDesc(Structure):
                 ("gn_partial", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("variant", c_int),
                 ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
                 ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long),
-                ("split_shift", c_int), ("x_plane_stride", c_long), ("w_plane_stride", c_long)]
+                ("split_shift", c_int), ("x_plane_stride", c_long), ("w_plane_stride", c_long),
+                ("out_planes", c_int), ("c_plane_stride", c_long)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)

@@ -47,6 +47,10 @@ struct GemmKP {
     int split_n1;
     long xplane_b, wplane_b;
     float split_scale;
+    // gp_gemm_desc.out_planes: C is written as the hi / lo' planes the NEXT split-operand GEMM reads (lo' cplane elements behind hi)
+    int out_planes;
+    long cplane;
+    float split_up;   // 2^S
 };
 
 template <typename T>
@@ -807,6 +811,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 const int m = mb + j * 32 + row;
                 if (m < p.M && nok) {
                     const f32x4 o = epi_apply<RT>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
+                    if (SPL && p.out_planes) {   // hi = fp16(o), lo' = fp16((o - hi) 2^S): what gp_split_planes would make of the fp32 result
+                        half4 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = (half_t)o[e];
+                            lv[e] = (half_t)((o[e] - (float)hv[e]) * p.split_up);
+                        }
+                        half_t* ch = reinterpret_cast<half_t*>(p.C) + (long)m * p.ldc + en;
+                        *reinterpret_cast<half4*>(ch) = hv;
+                        *reinterpret_cast<half4*>(ch + p.cplane) = lv;
+                    } else
                     if (p.dbg != 4 || o[0] == 12345.678f) store4<RT>(p, m, en, o);
                     gsum += (o[0] + o[1]) + (o[2] + o[3]);
                     gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
@@ -1362,6 +1377,13 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(d->x_plane_stride % 8 == 0 && d->w_plane_stride % 8 == 0, "gp_gemm: plane strides must keep 16-byte alignment");
         p.xplane_b = d->x_plane_stride * 2; p.wplane_b = d->w_plane_stride * 2;
         p.split_scale = ldexpf(1.0f, -d->split_shift);
+        if (d->out_planes) {
+            GP_REQUIRE(d->c_plane_stride >= (long)d->M * d->ldc && d->c_plane_stride % 4 == 0 && d->splitk <= 1,
+                       "gp_gemm: out_planes needs c_plane_stride >= M * ldc (elements) and no split-K");
+            p.out_planes = 1; p.cplane = d->c_plane_stride; p.split_up = ldexpf(1.0f, d->split_shift);
+        }
+    } else {
+        GP_REQUIRE(!d->out_planes, "gp_gemm: out_planes belongs to the split-operand mode");
     }
     if (d->gn_partial) {
         GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
@@ -1415,7 +1437,12 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py); shorter M does not amortise the
             // 256 KB weight prologue per CU.  GP_GEMM_WREG=0: A/B switch
             if (wreg_ok && !split && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
-            else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            // (split-operand mode: the K loop is three times as long, which is what the ping-pong tile's fill / drain is weighed
+            // against; measured, scripts/split_variants.py: it wins from ~140 tiles of 256 x 256 up, below that the 128 x 128
+            // two-workgroups-per-CU tile does; the 256 x 128 tile never)
+            const long keff = split ? 3l * d->K : d->K;
+            if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
+            else if (d->N % 256 == 0 && keff >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
         else variant = 4;

@@ -153,10 +153,13 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
-         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, prefetch=None, _stamps=None):
+         ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, prefetch=None, _stamps=None, x_planes=False,
+         out_planes=False):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM.
-    prefetch = a tensor (the weights of the NEXT launch on this stream) to be pulled towards the caches meanwhile: a hint."""
+    prefetch = a tensor (the weights of the NEXT launch on this stream) to be pulled towards the caches meanwhile: a hint.
+    w a SplitW: split-operand mode (fp32 x / out, fp16 hi + lo' operand planes).  out_planes: `out` (fp32 (M, N) storage) receives
+    the result as the two fp16 planes [hi (M, N) | lo' (M, N)] instead of fp32 values; x_planes: `x` is such a container."""
     split = isinstance(w, SplitW)
     dt = x.dtype
     if split:
@@ -193,15 +196,26 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
         else:
             rows, cols, ld = M, K, ldx
             ldx = K                      # the planes are dense
-        xptr = split_planes(x, rows, cols, ld, shift=w.shift).data_ptr()
+        if x_planes:     # written by the previous split-operand GEMM (out_planes): [hi (rows, cols) | lo' (rows, cols)] in x's storage
+            if conv is not None or ld != cols or not x.is_contiguous():
+                raise RuntimeError("gemm(x_planes): dense plain-GEMM operand only")
+        else:
+            xptr = split_planes(x, rows, cols, ld, shift=w.shift).data_ptr()
         d.split_shift, d.x_plane_stride, d.w_plane_stride = w.shift, rows * cols, N * K
         out_f32 = 1
+        if out_planes:
+            if not out.is_contiguous() or out.shape[-1] != N or (ldc is not None and ldc != N) or splitk not in (None, 1):
+                raise RuntimeError("gemm(out_planes): dense (M, N) fp32 storage, no split-K")
+            d.out_planes, d.c_plane_stride = 1, M * N
+            splitk = 1
     else:
         out_f32 = 1 if (out.dtype == torch.float32 and dt != torch.float32) else 0
         if out.dtype not in (dt, torch.float32):
             raise TypeError("gemm: out dtype must equal x dtype or float32")
     ldc = out.stride(0) if ldc is None else ldc
     esz = 2 if code == GP_F16 else 4
+    if (x_planes or out_planes) and not split:
+        raise RuntimeError("gemm: x_planes / out_planes belong to the split-operand mode")
     if splitk is None:
         splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 4) and gn is None and ln is None) else 1
     d.X, d.W, d.C = xptr, w.data_ptr(), out.data_ptr()

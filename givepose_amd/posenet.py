@@ -390,9 +390,12 @@ class PoseNet(nn.Module):
                     continue
                 # every GEMM-class launch may pull the weights of a later one towards the caches while it runs
                 # (gp_gemm_desc.prefetch: a hint; the 128x128-tile GEMMs run 10-25 % longer on weights that come from HBM)
-                ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU, prefetch=W[q + "fc2_w"])
+                # (split-operand mode: fc1 writes the hidden tensor as the fp16 planes fc2 reads -- no fp32 round trip, no split pass)
+                pl = self.split_gemm
+                ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU, prefetch=W[q + "fc2_w"],
+                         out_planes=pl)
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
-                         gamma=W[q + "gamma"], residual=x2d,
+                         gamma=W[q + "gamma"], residual=x2d, x_planes=pl,
                          prefetch=W.get(f"ds{s + 1}.w") if b == n - 1 else None)
         if cfg.main_backbone == "convnext":
             feat = x                                # (B,8,8,1024)

@@ -151,6 +151,10 @@ typedef struct gp_gemm_desc {
      *   residual (if any) is fp32; ldx / Cin / K address one plane; variant 0 / 4 / 7 / 8 / 10. */
     int split_shift;
     long x_plane_stride, w_plane_stride;
+    /* split-operand mode only, out_planes != 0: C is written as fp16 planes (hi at C, lo' c_plane_stride elements behind it,
+     * row stride ldc in fp16 elements) -- the X operand of the next split-operand gp_gemm -- instead of fp32; no split-K. */
+    int out_planes;
+    long c_plane_stride;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 

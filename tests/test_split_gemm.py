@@ -170,3 +170,22 @@ def test_split_mode_bs64_matches_oracle(use_dcn):
     assert torch.equal(out["mask"].cpu(), ref["mask"])
     assert err["rot"] < 1e-4 and err["trans"] < 1e-4 and err["size"] < 1e-4
     assert err["nocs_coor"] < 2e-4 and err["ivfc_coor"] < 2e-4
+
+
+@pytest.mark.parametrize("variant", [0, 7, 8, 10])
+def test_split_gemm_out_planes_feed_the_next_gemm(variant):
+    """fc1 -> GELU -> planes -> fc2 (+ layer scale, shortcut): the hidden tensor never exists in fp32."""
+    o = ops()
+    M, C = 1024, 128
+    x, w1, b1 = rnd(M, C, seed=1), rnd(4 * C, C, seed=2, scale=C ** -0.5), rnd(4 * C, seed=3)
+    w2, b2, gamma, res = rnd(C, 4 * C, seed=4, scale=(4 * C) ** -0.5), rnd(C, seed=5), rnd(C, seed=6), rnd(M, C, seed=7)
+    hid = F.gelu(x.double() @ w1.double().t() + b1.double())
+    ref = res.double() + gamma.double() * (hid @ w2.double().t() + b2.double())
+    h = torch.empty(M, 4 * C, dtype=torch.float32, device="cuda")
+    o.gemm(x.cuda(), o.split_weights(w1, "cuda"), h, bias=b1.cuda(), epilogue=o.EPI_GELU, variant=variant, out_planes=True)
+    planes = h.view(torch.float16).reshape(2, M, 4 * C).cpu().double()
+    assert rel64(planes[0] + planes[1] * 2.0 ** -o.SPLIT_SHIFT, hid) < TOL
+    out = res.clone().cuda()
+    o.gemm(h, o.split_weights(w2, "cuda"), out, bias=b2.cuda(), epilogue=o.EPI_SCALE_RES, gamma=gamma.cuda(), residual=out,
+           variant=variant, x_planes=True)
+    assert rel64(out, ref) < TOL
