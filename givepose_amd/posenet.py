@@ -500,6 +500,12 @@ class PoseNet(nn.Module):
         """The stream slot `slot`'s hipGraph is launched on (None before its first use / without use_graph)."""
         return self._streams.get(slot)
 
+    def ensure_stream(self, slot=0, device="cuda"):
+        """As stream(), creating it if need be (callers that queue work in front of the slot's next forward)."""
+        if slot not in self._streams:
+            self._streams[slot] = torch.cuda.Stream(device=torch.device(device))
+        return self._streams[slot]
+
     @torch.no_grad()
     def forward_device(self, data, device="cuda", slot=0, wait=True):
         """Runs the path and returns views of the static output buffers, all on the device (no D->H sync).

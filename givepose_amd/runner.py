@@ -11,11 +11,21 @@ from . import dist as gd
 
 
 class ShardRunner:
-    def __init__(self, net, batch, device, world=1, inflight=None):
+    """h2d: None = the inputs stay resident in HBM (what bench.py's `value` measures); "crops" = every step first brings its
+    fp32 crops from pinned host memory; "frames" = uint8 frames + masks + boxes travel and `gp_crop_rois` makes the crops on the
+    device (givepose_amd.preprocess).  Either way the transfer of a step runs on a COPY stream into a per-slot staging
+    buffer -- it depends only on the staging buffer's previous consumer, not on the slot's previous forward -- and the
+    slot's stream turns it into the model's static inputs (one device copy / the crop kernel) right in front of its
+    hipGraph, so the PCIe traffic of step n + 1 overlaps the kernels of step n."""
+
+    def __init__(self, net, batch, device, world=1, inflight=None, h2d=None, frame_hw=(480, 640)):
         self.net, self.B, self.dev, self.world = net, batch, torch.device(device), world
         self.NF = max(1, net.inflight if inflight is None else inflight)
         if self.NF > 1 and not net.use_graph:
             raise ValueError("batches in flight need the hipGraph path (per-slot streams)")
+        if h2d not in (None, "crops", "frames"):
+            raise ValueError("h2d: None | 'crops' | 'frames'")
+        self.h2d = h2d
         self.statics = [net.static_inputs(batch, self.dev, slot=i) for i in range(self.NF)]
         self.poses = [torch.empty(batch, gd.POSE_WIDTH, device=self.dev) for _ in range(self.NF)]
         self.gathered = [torch.empty(world * batch, gd.POSE_WIDTH, device=self.dev) for _ in range(self.NF)] if world > 1 else None
@@ -23,12 +33,61 @@ class ShardRunner:
         self.packed = [None] * self.NF      # event: the previous poses of slot i have been packed (its outputs may be overwritten)
         self.count = 0
         self.last = None
+        if h2d:
+            self.copy = torch.cuda.Stream(device=self.dev)
+            self.pinned = [None] * self.NF      # slot -> {name: pinned host tensor}
+            self.staging = [None] * self.NF     # slot -> {name: device tensor the copy stream fills}
+            self.staged_free = [None] * self.NF  # event: the slot stream has consumed the staging buffers
+            self.host_bytes = 0
+            if h2d == "frames":
+                from .preprocess import RoiCropper
+                self.cropper = RoiCropper(frame_hw[0], frame_hw[1], self.dev)
+                self.boxes = [None] * self.NF
 
     def load(self, slot, host_batch):
-        """Fill slot `slot`'s device-resident inputs from a dict of numpy arrays / tensors."""
+        """Fill slot `slot`'s device-resident inputs from a dict of numpy arrays / tensors (and, with h2d = "crops", keep a
+        pinned host copy that every step transfers again)."""
         for k, v in host_batch.items():
             t = torch.as_tensor(v)
             self.statics[slot][k].copy_(t.reshape(self.statics[slot][k].shape))
+        if self.h2d == "crops":
+            self.pinned[slot] = {k: torch.as_tensor(v).reshape(self.statics[slot][k].shape).to(torch.float32).contiguous().pin_memory()
+                                 for k, v in host_batch.items()}
+            self.staging[slot] = {k: torch.empty_like(self.statics[slot][k]) for k in host_batch}
+            self.host_bytes = sum(v.numel() * v.element_size() for v in self.pinned[slot].values())
+
+    def load_frames(self, slot, frames_u8, masks_u8, frame_idx, mask_idx, boxes, scalars):
+        """h2d = "frames": the uint8 frames (F,H,W,3) / masks (B,H,W) and detection boxes of slot `slot`; `scalars` = the inputs
+        the crop kernel does not produce (cam_K, mean_size), kept resident."""
+        assert self.h2d == "frames"
+        for k, v in scalars.items():
+            self.statics[slot][k].copy_(torch.as_tensor(v).reshape(self.statics[slot][k].shape))
+        self.pinned[slot] = {"frames": torch.as_tensor(frames_u8).contiguous().pin_memory(), "masks": torch.as_tensor(masks_u8).contiguous().pin_memory()}
+        self.staging[slot] = {k: torch.empty_like(v, device=self.dev) for k, v in self.pinned[slot].items()}
+        self.boxes[slot] = (list(frame_idx), list(mask_idx), boxes)
+        self.host_bytes = sum(v.numel() * v.element_size() for v in self.pinned[slot].values()) + len(frame_idx) * 120
+
+    def _bring_inputs(self, i, cur):
+        """Copy stream: host -> staging (waits only for the staging buffer's last consumer); slot stream: staging -> static inputs."""
+        with torch.cuda.stream(self.copy):
+            if self.staged_free[i] is not None:
+                self.copy.wait_event(self.staged_free[i])
+            for k, v in self.pinned[i].items():
+                self.staging[i][k].copy_(v, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy)
+        s = self.net.ensure_stream(i, self.dev) if self.net.use_graph else cur
+        s.wait_event(ready)
+        with torch.cuda.stream(s):
+            if self.h2d == "frames":
+                fi, mi, boxes = self.boxes[i]
+                self.cropper(self.staging[i]["frames"], self.staging[i]["masks"], fi, mi, boxes, out=self.statics[i])
+            else:
+                for k, v in self.staging[i].items():
+                    self.statics[i][k].copy_(v, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.staged_free[i] = ev
 
     def step(self):
         """One pass of the whole path over one batch; consecutive steps use consecutive slots and overlap on the device
@@ -38,6 +97,8 @@ class ShardRunner:
         cur = torch.cuda.current_stream(self.dev)
         if self.packed[i] is not None:
             cur.wait_event(self.packed[i])          # forward_device orders the slot stream after `cur`
+        if self.h2d:
+            self._bring_inputs(i, cur)
         out = self.net.forward_device(self.statics[i], self.dev, slot=i, wait=self.NF == 1)
         if self.world > 1:
             done = torch.cuda.Event()
@@ -97,3 +158,22 @@ def rank_selfcheck(rank, world, port, queue, batch=8, steps=6, inflight=2, backe
     except Exception as e:   # the parent must never wait for a dead rank
         import traceback
         queue.put((rank, "error: " + repr(e) + "\n" + traceback.format_exc(), None, None))
+
+
+def run_cli(argv, env_updates, queue, timeout=900):
+    """Run a command line in a child of THIS process and report (returncode, stdout, stderr tail) through `queue`.  For tests
+    that must start a program from a process that never touched the GPU (a GPU-initialised process must not fork + exec on
+    this pool): the caller starts this function through the multiprocessing fork server."""
+    import os
+    import subprocess
+    env = dict(os.environ)
+    for k, v in env_updates.items():
+        if v is None:
+            env.pop(k, None)
+        else:
+            env[k] = v
+    try:
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout)
+        queue.put((r.returncode, r.stdout, r.stderr[-4000:]))
+    except Exception as e:
+        queue.put((-1, "", repr(e)))

@@ -1,0 +1,42 @@
+"""`python bench.py --gpus 2` with no torchrun environment starts its own rank processes (before anything touches the GPU) and
+fails when a rank fails.  GPU: the two-rank control flow on the one GPU of the box (GP_BENCH_REHEARSE=1: gloo, both ranks on
+cuda:0 -- the numbers mean nothing, the driver's real runs use RCCL with one rank per GPU).  CPU: the launcher alone."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spawn_ranks_propagates_failure(tmp_path, monkeypatch):
+    """The launcher part alone (no GPU): children that exit non-zero make the parent exit non-zero and stop the others."""
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\nr = int(os.environ['RANK'])\nassert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "time.sleep(30 if r == 2 else 0.2)\nsys.exit(7 if r == 1 else 0)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(script) if p == str(script) else os.path.normpath(p))
+    assert bench.spawn_ranks(3, []) == 7          # returns long before rank 2's 30 s: it was terminated
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_without_torchrun():
+    import multiprocessing as mp
+    from givepose_amd.runner import run_cli
+    ctx = mp.get_context("forkserver")        # started in conftest.pytest_configure before any GPU call: bench.py is exec'ed from a clean process
+    q = ctx.Queue()
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "8", "--inflight", "2",
+            "--no-cpu-baseline", "--no-roofline", "--no-parity"]
+    p = ctx.Process(target=run_cli, args=(argv, {"GP_BENCH_REHEARSE": "1", "WORLD_SIZE": None, "RANK": None, "LOCAL_RANK": None}, q, 700))
+    p.start()
+    rc, out, err = q.get(timeout=800)
+    p.join(30)
+    assert rc == 0, err
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["overlap_check"] == {"slots": 2, "ranks": 2, "poses_bitwise_equal_to_serial_replay": True}

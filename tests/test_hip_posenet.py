@@ -128,7 +128,7 @@ def oracle64():
             cfg = PoseNetConfig(use_dcn=use_dcn)
             data = _batch(64, 640)
             torch.set_num_threads(min(16, torch.get_num_threads()))
-            cache[use_dcn] = (data, O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg))
+            cache[use_dcn] = (data, O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg, return_intermediates=True))
         return cache[use_dcn]
     return get
 
@@ -153,6 +153,8 @@ def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
     net = PoseNet(PoseNetConfig(use_dcn=use_dcn), dtype=torch.float16, seed=0, use_graph=True).cuda()
     for _ in range(3):
         out = net(data, "cuda")
+    dev_out = net.forward_device(data)
+    rot6d = dev_out["rot6d"].float().cpu()
     err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print("fp16 bs64", repr(use_dcn), err)
     assert torch.equal(out["mask"].cpu(), ref["mask"])
@@ -160,11 +162,17 @@ def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
     # fp16 operands cannot meet 1e-4 at all -- tests/precision_model.py, DESIGN.md 5c.  Per crop the error of R is small
     # (median 3.5e-3, 90th percentile 9e-3 over the 64 crops); the rot6d -> R normalisation amplifies the fp16 error of the
     # one or two least well-conditioned crops, and THAT maximum is chaotic: numerically equivalent builds (e.g. the fp32-accurate
-    # stem on VALU or on MFMA) move it between 2.3e-2 and 6.2e-2.  So: the distribution tightly, the maximum loosely.
+    # stem on VALU or on MFMA) move it between 2.3e-2 and 6.2e-2.  A regression in any fp16 kernel must not hide behind that
+    # crop, so the bound that carries the test is on what the network itself computes -- the rot6d logits BEFORE the
+    # normalisation, relative to their scale (measured 4e-3 ... 6e-3) -- plus the distribution of |dR| up to its 99th
+    # percentile; the maximum only gets the ceiling the worst conditioning seen explains (6.2e-2).
     per_crop = (out["rot"].cpu() - ref["rot"]).abs().reshape(out["rot"].shape[0], -1).max(1).values.sort().values
-    print("fp16 bs64 per-crop |dR|: median %.4f p90 %.4f max %.4f" % (float(per_crop[32]), float(per_crop[57]), float(per_crop[-1])))
-    assert float(per_crop[32]) < 8e-3 and float(per_crop[57]) < 2e-2
-    assert err["rot"] < 1.2e-1 and err["size"] < 3e-2
+    r6 = float((rot6d - ref["rot6d"]).abs().max() / ref["rot6d"].abs().max())
+    print("fp16 bs64 per-crop |dR|: median %.4f p90 %.4f p99 %.4f max %.4f; rot6d logits rel %.2e" %
+          (float(per_crop[32]), float(per_crop[57]), float(per_crop[62]), float(per_crop[-1]), r6))
+    assert r6 < 1.5e-2
+    assert float(per_crop[32]) < 8e-3 and float(per_crop[57]) < 2e-2 and float(per_crop[62]) < 5e-2
+    assert err["rot"] < 8e-2 and err["size"] < 3e-2
     assert err["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max()))
 
 
@@ -326,3 +334,29 @@ def test_attention_encoder_variant_matches_oracle(dtype, tol):
     err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print("att", dtype, err)
     assert all(v < tol for v in err.values()), err
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("split", 2e-4), ("f16", 5e-2)])
+def test_attention_encoder_variant_bs32_matches_oracle(mode, tol):
+    """BASELINE configs[3] at ITS batch: nocsmap_encoder='att' (the in-repo analogue of the DINOv2 / attention variant, SURVEY.md
+    0.2) with 32 crops, hipGraph replay as bench.py runs it, against the oracle -- all three modes."""
+    from givepose_amd import PoseNet, synth
+    from givepose_amd.config import PoseNetConfig
+    from oracle import posenet_ref as O
+    cfg = PoseNetConfig(nocsmap_encoder="att")
+    kw = {"f32": dict(dtype=torch.float32), "split": dict(dtype=torch.float32, split_gemm=True), "f16": dict(dtype=torch.float16)}[mode]
+    net = PoseNet(cfg, seed=0, use_graph=True, **kw).cuda()
+    data = _batch(32, 1932)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = O.posenet_forward_ref(O.load_params(synth.synth_state_dict(cfg, 0)), data, cfg)
+    for _ in range(3):
+        out = net(data, "cuda")
+    err = {k: float((out[k].cpu() - ref[k]).abs().max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
+    per = (out["rot"].cpu() - ref["rot"]).abs().reshape(32, -1).max(1).values.sort().values
+    print("att bs32", mode, err, "median |dR| %.2e" % float(per[16]))
+    assert torch.equal(out["mask"].cpu(), ref["mask"])
+    if mode == "f16":      # the worst crop's R is conditioning-bound (see test_fp16_bs64_close_to_oracle): bound the rest tightly
+        assert float(per[16]) < 8e-3 and float(per[28]) < 2.5e-2 and err["rot"] < 8e-2
+        assert all(err[k] < tol for k in ("trans", "size", "nocs_coor", "ivfc_coor")), err
+    else:
+        assert err["rot"] < 1e-4 and err["trans"] < 1e-4 and err["size"] < 1e-4 and err["nocs_coor"] < tol and err["ivfc_coor"] < tol, err

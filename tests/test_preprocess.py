@@ -123,3 +123,17 @@ def test_pred_rt_hip_vs_oracle():
     assert np.array_equal(rt1.cpu().numpy()[:, :3, :3], out["rot"].numpy())
     with pytest.raises(RuntimeError):
         PP.pred_rt(out)
+
+
+def test_vectorised_crop_params_equal_the_per_detection_form():
+    """crop_params (batched numpy, what the product runs per frame) against the per-detection form it was vectorised from:
+    bit for bit -- the inverse maps feed the kernel's fixed-point rounding."""
+    from givepose_amd import preprocess as P
+    rng = np.random.default_rng(3)
+    n = 300
+    y1, x1 = rng.integers(0, 200, n), rng.integers(0, 300, n)
+    b = np.stack([y1, x1, y1 + rng.integers(10, 400, n), x1 + rng.integers(10, 500, n)], 1).astype(np.float64)
+    b[:100] += rng.random((100, 4))
+    A, B = P.crop_params(b, 480, 640), P.crop_params_loop(b, 480, 640)
+    for k in A:
+        assert A[k].dtype == B[k].dtype and A[k].shape == B[k].shape and np.array_equal(A[k], B[k]), k
