@@ -161,6 +161,7 @@ def main():
                          "the line then says so in config.inputs and is not the metric's `value` (inputs resident)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f64", action="store_true", help="skip the float64 pass of the oracle (vs_float64: ~25 s of host time)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-h2d", action="store_true")
@@ -464,6 +465,21 @@ def main():
                                             "parity_mode is the mode that does")
         for key, pp in parity_out.items():
             line[key]["vs_reference"] = err_stats(pp.cpu(), refp)
+        # The fp32 CPU reference has its own rounding error, and on the worst-conditioned crop of a batch (rot6d -> R divides by
+        # the norm of the logits) it is of the order of the 1e-4 bar itself.  One pass of the oracle in float64 on the same
+        # crops tells the modes' own errors from the reference's: every mode, and the fp32 reference, against float64.
+        if not args.no_f64:
+            t0 = time.perf_counter()
+            P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
+            s64 = {k: (t.double() if t.is_floating_point() else t) for k, t in ((k, torch.from_numpy(v)) for k, v in synth.synth_batch(B, seed=1000).items())}
+            with torch.no_grad():
+                r64 = O.posenet_forward_ref(P64, s64, cfg)
+            t64 = gd.pack_poses(r64["rot"], r64["trans"], r64["size"], out=torch.empty(B, gd.POSE_WIDTH, dtype=torch.float64))
+            line["vs_float64"] = {"what": "max abs error of R / t / s against the oracle run in float64 on the same 64 crops (per-crop statistics for R)",
+                                  "reference_fp32_cpu": err_stats(refp, t64), "timed_mode": err_stats(mine[0].cpu(), t64),
+                                  "host_seconds": round(time.perf_counter() - t0, 1)}
+            for key, pp in parity_out.items():
+                line["vs_float64"][key] = err_stats(pp.cpu(), t64)
 
     if rank == 0:
         if commit:

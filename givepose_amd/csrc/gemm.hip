@@ -360,6 +360,96 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
                  : "memory");
 }
 
+// ---- generic epilogue of the tile kernels (any output type, edge tiles, split-operand mode), through a wave-private LDS
+//      slab (8 KB).  RT = element type of residual and output (fp32 in the split-operand mode); mb / nb = first row / column
+//      of the WAVE's tile.
+template <typename RT, int MT, int NT, bool SPL>
+__device__ __forceinline__ void epilogue_generic(const GemmKP& p, f32x4 (&acc)[NT][MT], char* slab, int mb, int nb, int lane) {
+    // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
+    //      Lane owns output columns n .. n+3 (fixed) of rows i*4 + (lane>>4); every global load (bias, gamma,
+    //      the whole residual tile in f16 mode) is issued before the first store.
+    const int fr = lane & 15, fq = lane >> 4;
+    const int en = nb + (lane & 15) * 4, er = lane >> 4;
+    const bool nok = en < p.N;
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
+    const bool sres = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
+    const f32x4 g4 = (p.epi == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
+    constexpr bool PRE = sizeof(RT) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
+    typename Res4<RT>::type r4[PRE ? MT / 2 : 1][8];
+    if (PRE) {
+#pragma unroll
+        for (int j = 0; j < MT / 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + j * 32 + i * 4 + er;
+                for (int e = 0; e < 4; ++e) r4[PRE ? j : 0][i][e] = 0;
+                if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<RT>(p, m, en);
+            }
+    }
+    float gsum = 0.f, gsq = 0.f;
+#pragma unroll
+    for (int j = 0; j < MT / 2; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = h * 16 + fr;
+                *reinterpret_cast<f32x4*>(slab + row * 256 + (((nt * 4 + fq) ^ (row & 7)) << 4)) = acc[nt][2 * j + h];
+            }
+#pragma unroll
+        for (int i0 = 0; i0 < 8; i0 += 4) {
+            if (!PRE) {   // fp32 storage: residual in batches of 4 rows (register budget)
+#pragma unroll
+                for (int i = i0; i < i0 + 4; ++i) {
+                    const int m = mb + j * 32 + i * 4 + er;
+                    for (int e = 0; e < 4; ++e) r4[0][i][e] = 0;
+                    if (sres && nok && m < p.M) r4[0][i] = load_res4<RT>(p, m, en);
+                }
+            }
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) {
+                const int row = i * 4 + er, chunk = lane & 15;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
+                const int m = mb + j * 32 + row;
+                if (m < p.M && nok) {
+                    const f32x4 o = epi_apply<RT>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
+                    if (SPL && p.out_planes) {   // hi = fp16(o), lo' = fp16((o - hi) 2^S): what gp_split_planes would make of the fp32 result
+                        half4 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = (half_t)o[e];
+                            lv[e] = (half_t)((o[e] - (float)hv[e]) * p.split_up);
+                        }
+                        half_t* ch = reinterpret_cast<half_t*>(p.C) + (long)m * p.ldc + en;
+                        *reinterpret_cast<half4*>(ch) = hv;
+                        *reinterpret_cast<half4*>(ch + p.cplane) = lv;
+                    } else
+                    if (p.dbg != 4 || o[0] == 12345.678f) store4<RT>(p, m, en, o);
+                    gsum += (o[0] + o[1]) + (o[2] + o[3]);
+                    gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                }
+            }
+        }
+        // fused GroupNorm statistics: one (sum, sum of squares) per 64 output rows and channel group, fixed order
+        if (p.gn_partial && (j & 1)) {
+            float a = gsum, q = gsq;
+            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+            if (p.gn_cpg == 8) { a += __shfl_xor(a, 1, 64); q += __shfl_xor(q, 1, 64); }
+            const int mrow = mb + (j - 1) * 32;
+            if (er == 0 && nok && mrow < p.M && (p.gn_cpg == 4 || (lane & 1) == 0)) {
+                const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
+                const int b = mrow / p.gn_hw, ch = (mrow - b * p.gn_hw) >> 6;
+                float* o = p.gn_partial + (((long)b * cpi + ch) * G + en / p.gn_cpg) * 2;
+                o[0] = a;
+                o[1] = q;
+            }
+            gsum = gsq = 0.f;
+        }
+    }
+}
+
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP pin) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
@@ -761,90 +851,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             return;
         }
     }
-    // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
-    //      Lane owns output columns n .. n+3 (fixed) of rows i*4 + (lane>>4); every global load (bias, gamma,
-    //      the whole residual tile in f16 mode) is issued before the first store.
-    char* slab = smem + wave * 8192;
-    const int en = n0 + wn * NT * 16 + (lane & 15) * 4, er = lane >> 4;
-    const int mb = m0 + wm * MT * 16;
-    const bool nok = en < p.N;
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
-    const bool sres = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
-    const f32x4 g4 = (p.epi == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
-    constexpr bool PRE = sizeof(RT) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
-    typename Res4<RT>::type r4[PRE ? MT / 2 : 1][8];
-    if (PRE) {
-#pragma unroll
-        for (int j = 0; j < MT / 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = mb + j * 32 + i * 4 + er;
-                for (int e = 0; e < 4; ++e) r4[PRE ? j : 0][i][e] = 0;
-                if (sres && nok && m < p.M) r4[PRE ? j : 0][i] = load_res4<RT>(p, m, en);
-            }
-    }
-    float gsum = 0.f, gsq = 0.f;
-#pragma unroll
-    for (int j = 0; j < MT / 2; ++j) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int row = h * 16 + fr;
-                *reinterpret_cast<f32x4*>(slab + row * 256 + (((nt * 4 + fq) ^ (row & 7)) << 4)) = acc[nt][2 * j + h];
-            }
-#pragma unroll
-        for (int i0 = 0; i0 < 8; i0 += 4) {
-            if (!PRE) {   // fp32 storage: residual in batches of 4 rows (register budget)
-#pragma unroll
-                for (int i = i0; i < i0 + 4; ++i) {
-                    const int m = mb + j * 32 + i * 4 + er;
-                    for (int e = 0; e < 4; ++e) r4[0][i][e] = 0;
-                    if (sres && nok && m < p.M) r4[0][i] = load_res4<RT>(p, m, en);
-                }
-            }
-#pragma unroll
-            for (int i = i0; i < i0 + 4; ++i) {
-                const int row = i * 4 + er, chunk = lane & 15;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
-                const int m = mb + j * 32 + row;
-                if (m < p.M && nok) {
-                    const f32x4 o = epi_apply<RT>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
-                    if (SPL && p.out_planes) {   // hi = fp16(o), lo' = fp16((o - hi) 2^S): what gp_split_planes would make of the fp32 result
-                        half4 hv, lv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            hv[e] = (half_t)o[e];
-                            lv[e] = (half_t)((o[e] - (float)hv[e]) * p.split_up);
-                        }
-                        half_t* ch = reinterpret_cast<half_t*>(p.C) + (long)m * p.ldc + en;
-                        *reinterpret_cast<half4*>(ch) = hv;
-                        *reinterpret_cast<half4*>(ch + p.cplane) = lv;
-                    } else
-                    if (p.dbg != 4 || o[0] == 12345.678f) store4<RT>(p, m, en, o);
-                    gsum += (o[0] + o[1]) + (o[2] + o[3]);
-                    gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-                }
-            }
-        }
-        // fused GroupNorm statistics: one (sum, sum of squares) per 64 output rows and channel group, fixed order
-        if (p.gn_partial && (j & 1)) {
-            float a = gsum, q = gsq;
-            a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
-            a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
-            if (p.gn_cpg == 8) { a += __shfl_xor(a, 1, 64); q += __shfl_xor(q, 1, 64); }
-            const int mrow = mb + (j - 1) * 32;
-            if (er == 0 && nok && mrow < p.M && (p.gn_cpg == 4 || (lane & 1) == 0)) {
-                const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
-                const int b = mrow / p.gn_hw, ch = (mrow - b * p.gn_hw) >> 6;
-                float* o = p.gn_partial + (((long)b * cpi + ch) * G + en / p.gn_cpg) * 2;
-                o[0] = a;
-                o[1] = q;
-            }
-            gsum = gsq = 0.f;
-        }
-    }
+    epilogue_generic<RT, MT, NT, SPL>(p, acc, smem + wave * 8192, m0 + wm * MT * 16, n0 + wn * NT * 16, lane);
 }
 
 // =====================================================================================================
@@ -884,7 +891,10 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {   // as wait_vmcnt for cou
 #undef GP_WV
 }
 
-template <int WIMG, int NS>
+// SPL (split-operand mode, GemmKP::split_n1): the (chunk, tap) loop runs three times -- X_hi windows against W_lo' rows, X_lo'
+// against W_hi, then (accumulators scaled by 2^-S) X_hi against W_hi -- as one stream of 3 * NCC chunks through the same W
+// ring and window double buffer; fp32 output through the generic epilogue.
+template <int WIMG, int NS, bool SPL = false>
 __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     constexpr int MT = 8, NT = 4, BM = 256, BN = 256, LEAD = NS - 2;
     // window row pitch WW: a multiple of 8 pixels, so that a kh shift never changes bit 2 of the window pixel index
@@ -908,7 +918,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     const int m0 = tile * BM;
     const int img = m0 / (p.H * WIMG), h0 = (m0 - img * p.H * WIMG) / WIMG;
-    const int Cin = p.Cin, NCC = Cin >> 5, NSTG = 9 * NCC;
+    const int Cin = p.Cin, NCC = Cin >> 5, NG = SPL ? 3 * NCC : NCC, NSTG = 9 * NG;   // NG chunks of 32 channels in all
 
     const half_t* __restrict__ X = reinterpret_cast<const half_t*>(p.X);
     const half_t* __restrict__ W = reinterpret_cast<const half_t*>(p.W);
@@ -937,15 +947,21 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         if (ok) xvalid |= 1u << j;
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
-    auto stage_w = [&](int buf, int cc, int tap) {      // W rows of K step (cc, tap): k offset tap * Cin + cc * 32
-        const char* base = reinterpret_cast<const char*>(W) + (tap * Cin + cc * 32) * 2;
+    auto stage_w = [&](int buf, int g, int tap) {      // W rows of K step (chunk g, tap): k offset tap * Cin + cc * 32
+        int cc = g;
+        long plane = 0;
+        if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 0 ? p.wplane_b : 0; }
+        const char* base = reinterpret_cast<const char*>(W) + plane + (tap * Cin + cc * 32) * 2;
         const unsigned d = lds0 + buf * WST + wave * 1024;
         glds16_s(base, woff[0], d);
         glds16_s(base, woff[1], d + 8192);
     };
-    auto stage_x = [&](int j, int cc) {        // one 16-pixel piece of the window of chunk cc
-        const unsigned d = lds0 + WIN0 + (cc & 1) * WINB + (wave + 8 * j) * 1024;
-        const char* src = ximg + xoff[j] + cc * 64;
+    auto stage_x = [&](int j, int g) {        // one 16-pixel piece of the window of chunk g
+        int cc = g;
+        long plane = 0;
+        if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 1 ? p.xplane_b : 0; }
+        const unsigned d = lds0 + WIN0 + (g & 1) * WINB + (wave + 8 * j) * 1024;
+        const char* src = ximg + plane + xoff[j] + cc * 64;
         glds16((xvalid >> j) & 1 ? src : zp, d);
     };
 
@@ -954,7 +970,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + a * 16 + fq * 4);
+        if (!SPL && p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + a * 16 + fq * 4);   // (SPL: the generic epilogue adds it)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
@@ -992,7 +1008,15 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 
     uint4 xf[MT], wf[NT];
     int st = 0, rbuf = 0, wbuf = LEAD, ops1 = 2, ops2 = 2;   // DMA ops issued one / two phases ago (W of steps 1..LEAD-1 at first)
-    for (int cc = 0; cc < NCC; ++cc) {
+    for (int cc = 0; cc < NG; ++cc) {      // (cc = global chunk index; SPL: segment cc / NCC)
+        if constexpr (SPL) {
+            if (cc == 2 * NCC) {            // the cross terms are complete: scale them once, exactly, then add x_hi w_hi
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] *= p.split_scale;
+            }
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++st) {
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -1009,7 +1033,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             // reads are two barriers back by tap 1), then the W rows of step st + 2; then wait for the own W of st + 1
             bool xi = false;
             if (tap >= 1 && tap <= 4) {
-                xi = cc + 1 < NCC && wave + 8 * (tap - 1) < NI && p.dbg != 1;
+                xi = cc + 1 < NG && wave + 8 * (tap - 1) < NI && p.dbg != 1;
                 if (xi) stage_x(tap - 1, cc + 1);
             }
             const bool wi = st + LEAD < NSTG && p.dbg != 1;
@@ -1040,12 +1064,16 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     }
     if (!grp) __builtin_amdgcn_s_barrier();
 
-    char* slab = smem + wave * 9216;
     const int mb = m0 + wm * 128, nb = wn * 64;
-    switch (p.epi) {
-        case GP_EPI_GELU: epilogue_lean<MT, NT, GP_EPI_GELU>(p, acc, slab, mb, nb, lane); break;
-        case GP_EPI_RELU: epilogue_lean<MT, NT, GP_EPI_RELU>(p, acc, slab, mb, nb, lane); break;
-        default: epilogue_lean<MT, NT, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
+    if constexpr (SPL) {
+        epilogue_generic<float, MT, NT, true>(p, acc, smem + wave * 8192, mb, nb, lane);
+    } else {
+        char* slab = smem + wave * 9216;
+        switch (p.epi) {
+            case GP_EPI_GELU: epilogue_lean<MT, NT, GP_EPI_GELU>(p, acc, slab, mb, nb, lane); break;
+            case GP_EPI_RELU: epilogue_lean<MT, NT, GP_EPI_RELU>(p, acc, slab, mb, nb, lane); break;
+            default: epilogue_lean<MT, NT, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
+        }
     }
 }
 
@@ -1451,11 +1479,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // ping-pong kernel would have been chosen)
     const bool win_ok = d->dtype == GP_F16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->N == 256 &&
                         d->Cin % 32 == 0 && (d->Win == 64 || d->Win == 32 || d->Win == 16) && d->H % (256 / d->Win) == 0 &&
-                        !d->out_f32 && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 &&
+                        (!d->out_f32 || split) && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 && !d->out_planes &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
     GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
-    GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 (got %d)", variant);
+    GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 16) {
@@ -1484,7 +1512,12 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         p.tiles_m = d->M / 256;
         p.tiles_n = 1;
         // 4-stage W ring, DMA lead 2 (a 5-stage / lead-3 instantiation spilled 43 registers and ran 1.6x slower)
-        if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        if (split) {
+            if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
+            else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv3_pp_kernel<16, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        }
+        else if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3_pp_kernel<16, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         GP_LAUNCH_CHECK("gp_gemm");

@@ -189,3 +189,30 @@ def test_split_gemm_out_planes_feed_the_next_gemm(variant):
     o.gemm(h, o.split_weights(w2, "cuda"), out, bias=b2.cuda(), epilogue=o.EPI_SCALE_RES, gamma=gamma.cuda(), residual=out,
            variant=variant, x_planes=True)
     assert rel64(out, ref) < TOL
+
+
+@pytest.mark.parametrize("B,H,Cin", [(2, 64, 256), (3, 32, 256), (5, 16, 256), (1, 64, 128)])
+def test_split_window_conv(B, H, Cin):
+    """The 3x3 LDS-window kernel (variant 13) in the split-operand mode: three passes over the (chunk, tap) loop, fp32 output,
+    fused GroupNorm statistics -- against float64 and against the tap-by-tap ping-pong kernel (variant 10)."""
+    o = ops()
+    Cout = 256
+    x = rnd(B, Cin, H, H, seed=21)
+    w = rnd(Cout, Cin, 3, 3, seed=22, scale=(Cin * 9) ** -0.5)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1).permute(0, 2, 3, 1)
+    xp = x.permute(0, 2, 3, 1).contiguous().cuda()
+    sw = o.split_weights(w.permute(0, 2, 3, 1).reshape(Cout, -1), "cuda")
+    hw = H * H
+    outs = {}
+    for v in (13, 10):
+        out = torch.empty(B, H, H, Cout, dtype=torch.float32, device="cuda")
+        part = torch.zeros(B * (hw // 64) * 32 * 2, dtype=torch.float32, device="cuda")
+        o.conv2d_nhwc(xp, sw, 3, 3, 1, 1, out=out, gn=(part, 32, hw), variant=v, epilogue=o.EPI_GELU if v == 13 and Cin == 128 else o.EPI_NONE)
+        if not (v == 13 and Cin == 128):
+            assert rel64(out, ref) < TOL, v
+            st = part.view(B, hw // 64, 32, 2).sum(1).cpu().double()
+            r = ref.reshape(B, hw, 32, Cout // 32)
+            assert float((st[..., 1] - (r * r).sum((1, 3))).abs().max()) < 1e-5 * float((r * r).sum((1, 3)).max())
+        else:
+            assert rel64(out, F.gelu(ref)) < TOL
+        outs[v] = out
