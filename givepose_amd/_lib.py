@@ -69,6 +69,7 @@ PROTOTYPES = {
     "gp_mask_resize_nearest": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "gp_crop_rois": ([_P] * 12 + [c_int] * 7 + [_P], c_int),
     "gp_pred_rt": ([_P] * 6 + [c_int, _P], c_int),
+    "gp_pack_poses": ([_P] * 4 + [c_int, _P], c_int),
     "gp_sn_stem": ([_P] * 4 + [c_int] * 3 + [_P], c_int),
     "gp_sn_pointwise": ([_P] * 6 + [c_long] + [c_int] * 4 + [_P], c_int),
     "gp_sn_depthwise": ([_P] * 4 + [c_int] * 7 + [_P], c_int),

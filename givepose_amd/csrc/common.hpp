@@ -84,9 +84,10 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 
 // GELU for fp16 storage: erf(x / sqrt 2) ~ xc * r(xc^2), xc = x clamped to +-4.4, r of degree 8 (minimax LP fit,
 // DESIGN.md section 5); max |GELU error| 4.1e-5 in fp32 Horner = 1/12 of an fp16 ulp at |x| ~ 1.
-// No transcendental, and written on 2-vectors so that hipcc emits v_pk_{mul,fma,max,min}_f32: a wave64 VALU
-// instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the fc1 epilogues and the
-// GroupNorm+GELU passes VALU bound.  The fp32 storage path keeps gelu_erf.
+// No transcendental: a wave64 VALU instruction costs 4 cycles per SIMD on gfx950 and the exact-erf form above made the
+// fc1 epilogues and the GroupNorm+GELU passes VALU bound.  Written on 2-vectors for historical reasons: the library is
+// built with `-target-feature -packed-fp32-ops` (givepose_amd/build.py), so every operation below is a plain
+// v_fma_f32 / v_mul_f32 per element -- same roundings, same results.  The fp32 storage path keeps gelu_erf.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Workgroup id -> work item so that each XCD (workgroup ids equal mod 8 share one, round-robin placement) owns ONE contiguous
 // run of the n items: XCD x of 8 gets items [x n/8, (x+1) n/8) (bijective for any n).  Every kernel of the ConvNeXt block
@@ -124,8 +125,8 @@ __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
     for (int k = 2; k < 9; ++k) p = __builtin_elementwise_fma(p, t, f32x2{GELU_H[k], GELU_H[k]});
     return x * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
 }
-// the same polynomial on NC 2-vectors walked in lock step: NC independent dependency chains, so the packed FMAs
-// issue back to back instead of waiting out each other's latency (fused MLP kernel, csrc/mlp.hip)
+// the same polynomial on NC 2-vectors walked in lock step: NC independent dependency chains, so the FMAs issue back to
+// back instead of waiting out each other's latency (fused MLP kernel, csrc/mlp.hip)
 template <int NC>
 __device__ __forceinline__ void gelu_poly2_xn(f32x2* x) {
     f32x2 xc[NC], t[NC], p[NC];
@@ -148,9 +149,9 @@ __device__ __forceinline__ void gelu_poly2_xn(f32x2* x) {
 __device__ __forceinline__ void gelu_poly2_x8(f32x2 (&x)[8]) { gelu_poly2_xn<8>(x); }
 // the same polynomial as 12 separable slices of one operation per element, for callers that hide it in the shadow of
 // MFMAs a slice at a time (gemm_wreg_kernel): slice S of chain c works on x[c] with the scratch xc[c], t[c], p[c].
-// Plain v_fma_f32 / v_mul_f32 from inline asm, NOT packed: beside MFMAs one v_pk_fma_f32 costs ~22 cycles more than two
-// v_fma_f32 (MI355X_MICROARCH.md, constants table), and hipcc packs whatever it can.  Same roundings as gelu_poly2
-// (IEEE fma / mul either way), so the results are bitwise those of the packed form.
+// Plain v_fma_f32 / v_mul_f32 from inline asm (the slices date from the time the library still allowed packed fp32 ops:
+// beside MFMAs one v_pk_fma_f32 costs ~22 cycles more than two v_fma_f32, MI355X_MICROARCH.md constants table; the asm
+// also pins the order).  Same roundings as gelu_poly2 (IEEE fma / mul either way): bitwise the same results.
 __device__ __forceinline__ float vfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float vfma_s(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c)); return d; }
 __device__ __forceinline__ float vmul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }

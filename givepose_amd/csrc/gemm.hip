@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     f32x2 v[NT * MT * 2];   // pre-activation values of the previous tile
     half_t* Cw = reinterpret_cast<half_t*>(p.C) + (m0 + fr) * (long)p.ldc + nb + fq * 4;
     // B fragments of a tile are read two K steps ahead of their MFMAs into a ring of three register pairs; SHADOW: the
-    // GELU of the previous tile (v) is issued in the shadow of the MFMAs, two packed VALU operations behind each MFMA
+    // GELU of the previous tile (v) is issued in the shadow of the MFMAs, slices of plain VALU operations behind each MFMA
     // (12 slices x 4 chains per half tile: K steps 0-7 carry chains 0-3, K steps 8-15 chains 4-7).  sched_barriers pin
     // the order: hipcc otherwise clusters the VALU work and waits lgkmcnt(0) in front of every MFMA pair.
     f32x2 gx[4], gt[4], gp[4];

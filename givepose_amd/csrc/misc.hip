@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     const int ppw = PXB / 4;
     for (int q = 0; q < ppw; ++q) {
         const int p = wave * ppw + q;
-        f32x2 a01 = {bv.x, bv.y};     // both channels of the lane in one v_pk_fma_f32 per tap
+        f32x2 a01 = {bv.x, bv.y};     // both channels of the lane side by side (two v_fma_f32 per tap: no packed fp32 ops in this build)
 #pragma unroll
         for (int row = 0; row < 12; ++row) {
             const f32x4 iv = *reinterpret_cast<const f32x4*>(&in_s[row][p * 4]);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 
 
 // The same stem on the matrix pipe (fp16 output, 64 output pixels of a row per workgroup): as a GEMM it is M = pixels, N = 128,
-// K = 48, and the VALU form above spends 48 packed FMAs per pixel and lane (45 us of the 87 at bs 64).  The fp32 image and
+// K = 48, and the VALU form above spends 48 two-channel FMA pairs per pixel and lane (45 us of the 87 at bs 64).  The fp32 image and
 // the fp32 taps are both split into fp16 hi + lo, and x_hi w_hi + x_lo w_hi + x_hi w_lo is accumulated in fp32 (the dropped
 // x_lo w_lo is 2^-22 of the product): the stem stays an fp32-accurate convolution, unlike the rest of the fp16 mode whose
 // weights are rounded once.  K order: k = c*16 + kh*4 + kw as in wt, padded to 64 (two 32-deep MFMA steps).
@@ -1114,4 +1114,27 @@ extern "C" int gp_split_planes(const float* x, void* planes, long rows, int cols
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, hi, hi + plane_stride, rows, cols / 8, ldx,
                        ldexpf(1.0f, split_shift));
     GP_LAUNCH_CHECK("gp_split_planes");
+}
+
+
+// =====================================================================================================
+// (R 9, t 3, s 3) -> one (B, 15) fp32 row per crop: the payload of the all-gather (givepose_amd/dist.py).  A library kernel
+// rather than three strided PyTorch copies, so that everything that runs on the communication stream beside the MFMA kernels
+// of the other slots is built with this library's flags.
+namespace {
+__global__ __launch_bounds__(256) void pack_poses_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ sz,
+                                                         float* __restrict__ out, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * 15) return;
+    const int b = i / 15, c = i - b * 15;
+    out[i] = c < 9 ? R[b * 9 + c] : c < 12 ? t[b * 3 + c - 9] : sz[b * 3 + c - 12];
+}
+}  // namespace
+
+extern "C" int gp_pack_poses(const float* R, const float* t, const float* size, float* out, int B, void* stream) {
+    GP_REQUIRE(R && t && size && out && B > 0, "gp_pack_poses: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_SMALL, 0.0, B * 120.0);
+    hipLaunchKernelGGL(pack_poses_kernel, dim3(cdiv(B * 15, 256)), dim3(256), 0, s, R, t, size, out, B);
+    GP_LAUNCH_CHECK("gp_pack_poses");
 }

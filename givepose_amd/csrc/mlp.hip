@@ -162,7 +162,8 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
 #pragma unroll
         for (int ct = 0; ct < GC; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + ct * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- GELU on the 16 values of this lane, as 8 independent packed chains walked in lock step, then fp16:
+        // ---- GELU on the 16 values of this lane, as 8 independent 2-element chains walked in lock step (plain v_fma_f32: the
+        //      library is built without packed fp32 ops), then fp16:
         //      the B fragments of GEMM2 (k-slot fq*8 + nt*4 + j)
         f32x2 v[8];
 #pragma unroll

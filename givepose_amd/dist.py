@@ -50,7 +50,13 @@ def pack_poses(rot, trans, size, out=None):
     """(B,3,3),(B,3),(B,3) -> (B,15) fp32 on rot's device."""
     B = rot.shape[0]
     if out is None:
-        out = torch.empty(B, POSE_WIDTH, dtype=torch.float32, device=rot.device)
+        out = torch.empty(B, POSE_WIDTH, dtype=rot.dtype if rot.dtype == torch.float64 else torch.float32, device=rot.device)
+    if rot.is_cuda and out.dtype == torch.float32 and all(x.dtype == torch.float32 and x.is_contiguous() for x in (rot, trans, size, out)):
+        import ctypes
+        from . import _lib       # one library kernel on the current stream (no PyTorch kernels beside the slots' MFMA kernels)
+        _lib.check(_lib.load().gp_pack_poses(rot.data_ptr(), trans.data_ptr(), size.data_ptr(), out.data_ptr(), B,
+                                            ctypes.c_void_p(torch.cuda.current_stream(rot.device).cuda_stream)), "gp_pack_poses")
+        return out
     out[:, :9] = rot.reshape(B, 9)
     out[:, 9:12] = trans
     out[:, 12:15] = size

@@ -12,6 +12,7 @@ Everything is channels-last on the device; the whole launch sequence of one forw
 in a hipGraph and replayed (``use_graph=True``).
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -79,6 +80,10 @@ class PoseNet(nn.Module):
             _register(self, name, t, not is_buf)
         self._packed = None       # device-side packed weights
         self.inflight = int(inflight)   # batches the caller keeps in flight (forward_device slots)
+        if self.inflight > 1 and os.environ.get("GP_PACKED_FP32") == "1":
+            # the A/B build with packed fp32 VALU ops: v_pk_fma_f32 results of one kernel's waves come out wrong beside another
+            # kernel's MFMA stream on the same SIMD -- only strictly serial launches are safe with it
+            raise RuntimeError("GP_PACKED_FP32=1 builds must not keep batches in flight (inflight > 1)")
         self._plans = {}          # (B, slot) -> buffers / graph
         self._streams = {}        # slot -> dedicated stream of the hipGraph path
         self.eval()

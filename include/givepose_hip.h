@@ -300,6 +300,9 @@ int gp_crop_rois(const unsigned char* frames, const unsigned char* masks, const 
 int gp_pred_rt(const float* R, const float* t, const float* size, const float* scale, float* pred_rt, float* pred_size,
                int B, void* stream);
 
+/* Per-crop pose row for the all-gather of the sharded path: out (B,15) fp32 = [R row-major 9 | t 3 | size 3]. */
+int gp_pack_poses(const float* R, const float* t, const float* size, float* out, int B, void* stream);
+
 /* ---- hipGraph capture of a launch sequence (launch-bound inner loop -> one graph launch) */
 int gp_graph_begin(void* stream);
 int gp_graph_end(void* stream, void** graph_exec_out);

@@ -72,6 +72,19 @@ def test_no_packed_fp32_instructions_in_the_library(tmp_path):
     assert n > 1000      # (the disassembly really is the library's: it is full of MFMAs)
 
 
+def test_no_packed_fp32_in_inline_asm_or_builtins():
+    """The compile flag that keeps packed fp32 ops out (-target-feature -packed-fp32-ops) does not reach hand-written asm
+    strings, and the disassembly test above only sees what this build instantiated: no source may spell one (reproduced on
+    ROCm 7.2 / gfx950, scripts/repro/pkfma_beside_mfma.hip; any v_pk_*_f32 form, mov included, is kept out)."""
+    src = os.path.join(ROOT, "givepose_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".hpp")):
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(src, f)).read())          # comments may name the instruction
+            assert not re.search(r"v_pk_\w+_f32|__builtin_amdgcn_pk_\w*f32", code), f
+    flags = open(os.path.join(ROOT, "givepose_amd", "build.py")).read()
+    assert "-packed-fp32-ops" in flags
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "givepose_amd")
     for dp, _, files in os.walk(pkg):
