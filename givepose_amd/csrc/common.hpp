@@ -60,6 +60,26 @@ template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
 template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
     *reinterpret_cast<uint4*>(p) = v.u;
 }
+// Split-operand planes as an OUTPUT format of the fp32 kernels that feed a split-operand GEMM (dtype = GP_F32 | GP_OUT_PLANES):
+// instead of 4 fp32 at element offset `off` of y, write hi = fp16(v) at half-offset `off` of the same storage and
+// lo' = fp16((v - hi) * 2^GP_SPLIT_SHIFT) `pl` halfs behind it (pl = elements of the dense output tensor; 0 = plain store).
+template <typename T> __device__ __forceinline__ void store16p(T* y, long off, const Vec16<T>& v, long pl) {
+    if constexpr (sizeof(T) == 4) {
+        if (pl) {
+            half4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (half_t)v.e[e];
+                l[e] = (half_t)((v.e[e] - (float)h[e]) * (float)(1 << GP_SPLIT_SHIFT));
+            }
+            half_t* b = reinterpret_cast<half_t*>(y) + off;
+            *reinterpret_cast<half4*>(b) = h;
+            *reinterpret_cast<half4*>(b + pl) = l;
+            return;
+        }
+    }
+    *reinterpret_cast<uint4*>(y + off) = v.u;
+}
 template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
     Vec16<T> v;
     v.u = make_uint4(0, 0, 0, 0);

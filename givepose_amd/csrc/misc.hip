@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x
 // index arithmetic and is VALU bound at 2.9 TB/s (scripts/gn_bench.py).
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W,
-                                                              int C, int ct_shift) {
+                                                              int C, int ct_shift, long pl) {
     constexpr int VEC = Vec16<T>::N;
     const int Ho = 2 * H, Wo = 2 * W, CT = 1 << ct_shift;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < VEC; ++e)
         o.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
-    store16<T>(y + (((long)(b * Ho + oy)) * Wo + ox) * C + cs * VEC, o);
+    store16p<T>(y, (((long)(b * Ho + oy)) * Wo + ox) * C + cs * VEC, o, pl);
 }
 
 // ------------------------------------------------------------------------------------- deconv col2im
@@ -865,21 +865,24 @@ extern "C" int gp_convnext_stem(const float* img, const float* w, const float* b
     GP_LAUNCH_CHECK("gp_convnext_stem");
 }
 
-extern "C" int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+extern "C" int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype_in, void* stream) {
     GP_REQUIRE(x && y && B > 0 && H > 1 && W > 1, "gp_upsample_bilinear2x: bad argument");
+    const int dtype = dtype_in & ~GP_OUT_PLANES;
     GP_DT_OK(dtype);
+    const long pl = (dtype_in & GP_OUT_PLANES) ? (long)B * 4 * H * W * C : 0;
     const int esz = dtype == GP_F16 ? 2 : 4, vec = 16 / esz;
     GP_REQUIRE(C % vec == 0, "gp_upsample_bilinear2x: C=%d", C);
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * 4 * H * W * (C / vec);
     gp_timing_before(s, GP_KC_ELEMENTWISE, 8.0 * total * vec, (double)B * H * W * C * esz * 5);
     const int ct = C / vec;
+    GP_REQUIRE(!pl || (dtype == GP_F32 && (ct & (ct - 1)) == 0 && 2 * H <= 65535 && B <= 65535), "gp_upsample_bilinear2x: GP_OUT_PLANES needs GP_F32 and C / 4 a power of two");
     if ((ct & (ct - 1)) == 0 && 2 * H <= 65535 && B <= 65535) {
         int sh = 0;
         while ((1 << sh) < ct) ++sh;
         dim3 grid(cdiv((long)2 * W * ct, 256), 2 * H, B);
-        if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_rows_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, H, W, C, sh);
-        else hipLaunchKernelGGL(upsample2x_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, sh);
+        if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_rows_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, H, W, C, sh, 0l);
+        else hipLaunchKernelGGL(upsample2x_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, sh, pl);
         GP_LAUNCH_CHECK("gp_upsample_bilinear2x");
     }
     if (dtype == GP_F16) hipLaunchKernelGGL(upsample2x_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)x, (half_t*)y, B, H, W, C);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, T* __restrict__ y, int H,
-                                                        int W, int C, float eps, int act, long n_pixels) {
+                                                        int W, int C, float eps, int act, long n_pixels, long pl) {
     constexpr int VEC = Vec16<T>::N, PPT = 8, R = KS / 2;
     __shared__ float red[4 * PPT];
     const int CT = C / VEC, PG = 256 / CT;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
             const float val = acc[p][e] * rstd * gw[e] + gb[e];
             o.set(e, act == GP_ACT_GELU ? gelu_for<T>(val) : apply_act(val, act));
         }
-        store16<T>(y + (pix0 + p) * C + cs * VEC, o);
+        store16p<T>(y, (pix0 + p) * C + cs * VEC, o, pl);
     }
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ lnw,
                                                                const float* __restrict__ lnb, T* __restrict__ y, int H,
-                                                               int W, int C, float eps, int dbg) {
+                                                               int W, int C, float eps, int dbg, long pl) {
     constexpr int VEC = Vec16<T>::N, SC = 16 * VEC, KS = 7, R = 3;
     constexpr int PPT = 2, SPR = 4;                  // 32 pixel-threads x 2 px: strips per tile row
     constexpr int TW = SPR * PPT, TH = 32 / SPR;     // 8 x 8 output tile, 8 waves (2 per SIMD)
@@ -286,14 +286,14 @@ __global__ __launch_bounds__(512) void dwconv7_ln_tiled_kernel(const T* __restri
             Vec16<T> o;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o.set(e, acc[s][p][e] * var[p] * gw[e] + gb[e]);
-            store16<T>(y + (((long)b * H + h0 + row) * W + w0 + col0 + p) * C + s * SC + slot * VEC, o);
+            store16p<T>(y, (((long)b * H + h0 + row) * W + w0 + col0 + p) * C + s * SC + slot * VEC, o, pl);
         }
     }
 }
 
 template <typename T, int NSLAB>
 void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B,
-                      int H, int W, int C, float eps, hipStream_t s, int dbg = 0) {
+                      int H, int W, int C, float eps, hipStream_t s, int dbg = 0, long pl = 0) {
     constexpr int NPX = 14 * 14, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
     const int LDS = (NSLAB > 1 ? 2 : 1) * (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024;
     static bool attr_set = false;
@@ -302,7 +302,7 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
         attr_set = true;
     }
     hipLaunchKernelGGL((dwconv7_ln_tiled_kernel<T, NSLAB>), dim3(B * (H / 8) * (W / 8)), dim3(512), LDS, s, (const T*)x,
-                       (const T*)wt, bias, lnw, lnb, (T*)y, H, W, C, eps, dbg);
+                       (const T*)wt, bias, lnw, lnb, (T*)y, H, W, C, eps, dbg, pl);
 }
 
 // ---------------------------------------------------------------------------- dw7x7 + LN on the matrix cores (fp16)
@@ -618,7 +618,7 @@ void launch_dw7_raw(const void* x, const void* wt, const float* bias, void* y, f
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ y,
-                                                        long rows, int C, float eps, int ldy) {
+                                                        long rows, int C, float eps, int ldy, long pl) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float red[4];
     const int CT = C / VEC, PG = 256 / CT;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) o.set(e, a[e] * rstd * gw[e] + gb[e]);
-    store16<T>(y + row * ldy + cs * VEC, o);
+    store16p<T>(y, row * ldy + cs * VEC, o, pl);
 }
 
 // ---------------------------------------------------------------------------- GroupNorm
@@ -754,7 +754,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ partial,
                                                        const float* __restrict__ w, const float* __restrict__ bb,
                                                        T* __restrict__ y, int HW, int C, int G, int act, int ldy,
-                                                       int chunks, float inv_count, float eps, int GN_PXB) {
+                                                       int chunks, float inv_count, float eps, int GN_PXB, long plane) {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float st[256][2];
     const int CT = C / VEC, PG = 256 / CT, cpg = C / G;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * GN_PXB, p1 = min(HW, p0 + GN_PXB);
     const T* xb = x + ((long)b * HW) * C + cs * VEC;
-    T* yb = y + ((long)b * HW) * ldy + cs * VEC;
+    const long yo = ((long)b * HW) * ldy + cs * VEC;
     // 4 pixels in flight per thread (the loop is otherwise one dependent HBM round trip per pixel); the first four
     // and the affine parameters are requested before the statistics are finalised, whose loads they then overlap
     Vec16<T> v[4];
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o.set(e, apply_act(cur[u].get(e) * sc[e] + sh[e], act));
             }
-            store16<T>(yb + (long)p * ldy, o);
+            store16p<T>(y, yo + (long)p * ldy, o, plane);
         }
     }
 }
@@ -1007,9 +1007,12 @@ static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups p
 
 extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w,
                             const float* ln_b, void* y, int B, int H, int W, int C, int KS, float eps, int act,
-                            long n_pixels, int dtype, void* stream) {
+                            long n_pixels, int dtype_in, void* stream) {
     GP_REQUIRE(x && wt && bias && ln_w && ln_b && y, "gp_dwconv_ln: null pointer");
+    const int dtype = dtype_in & ~GP_OUT_PLANES;
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_dwconv_ln: bad dtype");
+    GP_REQUIRE(!(dtype_in & GP_OUT_PLANES) || (dtype == GP_F32 && x != y), "gp_dwconv_ln: GP_OUT_PLANES needs GP_F32 and y != x");
+    const long pl = (dtype_in & GP_OUT_PLANES) ? (long)B * H * W * C : 0;    // lo' plane: one dense tensor behind hi
     const int esz = dtype == GP_F16 ? 2 : 4;
     GP_REQUIRE(ct_ok(C, esz) && C / (16 / esz) >= 16, "gp_dwconv_ln: unsupported C=%d", C);
     GP_REQUIRE(KS == 3 || KS == 7, "gp_dwconv_ln: KS=%d unsupported (3 or 7)", KS);
@@ -1043,16 +1046,16 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
             else if (nslab == 4) launch_dw7_tiled<half_t, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
             else done = false;   // C = 1024 in fp16: the 8-slab instantiation spilled to scratch (banned) -> strip kernel
         } else {
-            if (nslab == 2) launch_dw7_tiled<float, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-            else if (nslab == 4) launch_dw7_tiled<float, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-            else if (nslab == 8) launch_dw7_tiled<float, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
-            else if (nslab == 16) launch_dw7_tiled<float, 16>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
+            if (nslab == 2) launch_dw7_tiled<float, 2>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg, pl);
+            else if (nslab == 4) launch_dw7_tiled<float, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg, pl);
+            else if (nslab == 8) launch_dw7_tiled<float, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg, pl);
+            else if (nslab == 16) launch_dw7_tiled<float, 16>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg, pl);
             else done = false;
         }
         if (done) GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
     dim3 grid(cdiv(strips, PG));
-#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels)
+#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, pl)
     if (dtype == GP_F16) { if (KS == 7) GP_DW(half_t, 7); else GP_DW(half_t, 3); }
     else { if (KS == 7) GP_DW(float, 7); else GP_DW(float, 3); }
 #undef GP_DW
@@ -1073,19 +1076,22 @@ extern "C" int gp_dwconv7_raw_stats(const void* x, const void* wt, const float* 
 }
 
 extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void* y, long rows, int C, float eps,
-                            int ldy, int dtype, void* stream) {
+                            int ldy, int dtype_in, void* stream) {
     if (ldy <= 0) ldy = C;
     GP_REQUIRE(x && w && b && y && rows > 0, "gp_layernorm: bad argument");
+    const int dtype = dtype_in & ~GP_OUT_PLANES;
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_layernorm: bad dtype");
+    GP_REQUIRE(!(dtype_in & GP_OUT_PLANES) || (dtype == GP_F32 && x != y && ldy == C), "gp_layernorm: GP_OUT_PLANES needs GP_F32, y != x and a dense output");
+    const long pl = (dtype_in & GP_OUT_PLANES) ? rows * C : 0;
     const int esz = dtype == GP_F16 ? 2 : 4;
     GP_REQUIRE(ct_ok(C, esz), "gp_layernorm: unsupported C=%d", C);
     const int CT = C / (16 / esz), PG = 256 / CT;
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 8.0 * rows * C, (double)rows * C * esz * 2);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps, ldy);
+        hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps, ldy, 0l);
     else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps, ldy);
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps, ldy, pl);
     GP_LAUNCH_CHECK("gp_layernorm");
 }
 
@@ -1112,9 +1118,12 @@ extern "C" int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, 
 
 extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y,
                                   int B, int HW, int C, int G, float eps, int act, int ldy, int chunks_in,
-                                  int dtype, void* stream) {
+                                  int dtype_in, void* stream) {
     GP_REQUIRE(x && partial && w && b && y && B > 0 && HW > 0, "gp_groupnorm_apply: bad argument");
+    const int dtype = dtype_in & ~GP_OUT_PLANES;
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply: bad dtype");
+    GP_REQUIRE(!(dtype_in & GP_OUT_PLANES) || (dtype == GP_F32 && x != y && ldy == C), "gp_groupnorm_apply: GP_OUT_PLANES needs GP_F32, y != x and a dense output");
+    const long pl = (dtype_in & GP_OUT_PLANES) ? (long)B * HW * C : 0;
     const int esz = dtype == GP_F16 ? 2 : 4;
     GP_REQUIRE(ct_ok(C, esz) && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_apply: unsupported C=%d G=%d", C, G);
     GP_REQUIRE(ldy >= C && ldy % (16 / esz) == 0, "gp_groupnorm_apply: bad ldy=%d", ldy);
@@ -1125,9 +1134,9 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
     if (dtype == GP_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
+        hipLaunchKernelGGL(gn_apply_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, (half_t*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb, 0l);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb, pl);
     GP_LAUNCH_CHECK("gp_groupnorm_apply");
 }
 

@@ -197,8 +197,8 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
             rows, cols, ld = M, K, ldx
             ldx = K                      # the planes are dense
         if x_planes:     # written by the previous split-operand GEMM (out_planes): [hi (rows, cols) | lo' (rows, cols)] in x's storage
-            if conv is not None or ld != cols or not x.is_contiguous():
-                raise RuntimeError("gemm(x_planes): dense plain-GEMM operand only")
+            if ld != cols or not x.is_contiguous():
+                raise RuntimeError("gemm(x_planes): dense operand only")
         else:
             xptr = split_planes(x, rows, cols, ld, shift=w.shift).data_ptr()
         d.split_shift, d.x_plane_stride, d.w_plane_stride = w.shift, rows * cols, N * K
@@ -241,7 +241,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
 
 
 def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None,
-                residual=None, prefetch=None):
+                residual=None, prefetch=None, x_planes=False):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -250,7 +250,8 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
         out = torch.empty(B, Ho, Wo, w_packed.shape[0], dtype=x.dtype, device=x.device)
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
          residual=None if residual is None else residual.view(B * Ho * Wo, -1),
-         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn, prefetch=prefetch)
+         conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn, prefetch=prefetch,
+         x_planes=x_planes)
     return out
 
 
@@ -270,6 +271,22 @@ def dcnv3_forward_into(inp, offset, mask, out, K, stride, pad, dil, G, D, offset
                                 1 if mask_is_logits else 0, dtype_code(inp.dtype), dtype_code(offset.dtype), _stream()),
           "gp_dcnv3_forward")
     return out
+
+
+OUT_PLANES = 0x100     # include/givepose_hip.h GP_OUT_PLANES (fp32 producers writing split-operand planes; shift GP_SPLIT_SHIFT = 11)
+
+
+def _planes_code(t, out_planes, out=None):
+    """dtype code of an fp32 producer kernel, with GP_OUT_PLANES when its (dense) output is to be the hi / lo' planes a
+    split-operand gemm(..., x_planes=True) reads."""
+    code = dtype_code(t.dtype)
+    if out_planes:
+        if t.dtype != torch.float32 or SPLIT_SHIFT != 11:
+            raise TypeError("out_planes: float32 storage (split-operand mode) only")
+        if out is not None and out.data_ptr() == t.data_ptr():
+            raise RuntimeError("out_planes: the output must not alias the input")
+        code |= OUT_PLANES
+    return code
 
 
 def _any_dtype(t):
@@ -363,11 +380,13 @@ def convnext_mlp(x, w1, b1, w2p, b2, gamma, residual, out):
     return out
 
 
-def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels=None):
+def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels=None, out_planes=False):
     B, H, W_, C = x.shape
     n = B * H * W_ if n_pixels is None else n_pixels
+    if out_planes and n != B * H * W_:
+        raise RuntimeError("dwconv_ln(out_planes): whole tensor only")
     check(_L().gp_dwconv_ln(_ptr(_contig(x, "x")), _ptr(wt), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, C, KS,
-                            eps, act, n, dtype_code(x.dtype), _stream()), "gp_dwconv_ln")
+                            eps, act, n, _planes_code(x, out_planes, out), _stream()), "gp_dwconv_ln")
     return out
 
 
@@ -379,10 +398,10 @@ def dwconv7_raw_stats(x, wt, bias, out, stats):
     return out
 
 
-def layernorm(x, w, b, out, eps=1e-6, ldy=0):
+def layernorm(x, w, b, out, eps=1e-6, ldy=0, out_planes=False):
     C = x.shape[-1]
     rows = x.numel() // C
-    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, ldy, dtype_code(x.dtype), _stream()),
+    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, ldy, _planes_code(x, out_planes, out), _stream()),
           "gp_layernorm")
     return out
 
@@ -401,7 +420,7 @@ def groupnorm_chunks(B, HW):
     return _L().gp_groupnorm_chunks(B, HW)
 
 
-def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=False):
+def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=False, out_planes=False):
     """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed.  fused_stats: ``partial``
     was already filled by the producing gemm(..., gn=(partial, G, HW)) in 64-row chunks."""
     B, HW, C = x.shape
@@ -409,7 +428,8 @@ def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=Fal
     if not fused_stats:
         check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), B, HW, C, G, code, _stream()), "gp_groupnorm_stats")
     check(_L().gp_groupnorm_apply(_ptr(x), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, eps, act,
-                                  C if ldy is None else ldy, HW // 64 if fused_stats else 0, code, _stream()), "gp_groupnorm_apply")
+                                  C if ldy is None else ldy, HW // 64 if fused_stats else 0, _planes_code(x, out_planes, out), _stream()),
+          "gp_groupnorm_apply")
     return out
 
 
@@ -421,9 +441,9 @@ def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, part
                                       _stream()), "gp_groupnorm_apply_xyz")
 
 
-def upsample_bilinear2x(x, out):
+def upsample_bilinear2x(x, out, out_planes=False):
     B, H, W_, C = x.shape
-    check(_L().gp_upsample_bilinear2x(_ptr(_contig(x, "x")), _ptr(out), B, H, W_, C, dtype_code(x.dtype), _stream()),
+    check(_L().gp_upsample_bilinear2x(_ptr(_contig(x, "x")), _ptr(out), B, H, W_, C, _planes_code(x, out_planes, out), _stream()),
           "gp_upsample_bilinear2x")
     return out
 

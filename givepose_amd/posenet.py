@@ -304,34 +304,46 @@ class PoseNet(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ launch sequence
-    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None, fused=False):
-        """GroupNorm(32)+act in place (or into a concat target); fused: the producing GEMM already wrote the statistics."""
+    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None, fused=False, out_planes=False):
+        """GroupNorm(32)+act in place (or into a concat target); fused: the producing GEMM already wrote the statistics.
+        out_planes (split-operand mode): `out` (another buffer of x's shape) receives the result as the fp16 planes the next
+        conv reads."""
         B = x.shape[0]
         C = x.shape[-1]
         xv = x.view(B, -1, C)
-        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy, fused_stats=fused)
+        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy, fused_stats=fused, out_planes=out_planes)
 
     @staticmethod
     def _gnarg(buf, hw):
         return (buf["gn_partial"], 32, hw)
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
-        """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows."""
+        """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows.
+        Split-operand mode: whatever feeds a 3x3 conv (GroupNorm apply, bilinear upsample) writes the conv's fp16 operand planes
+        directly (out of place, into the level's other ping-pong buffer) instead of fp32 + a split pass."""
+        pl = self.split_gemm
         ops.gemm(feat2d, W[head + ".deconv_w"], buf["cols"], prefetch=W[f"{head}.c3_w"])
         y = ops.deconv_col2im(buf["cols"], buf["ya16"], B, 8, 8, 256)
-        self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
+        if pl:
+            self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf, out=buf["yb16"].view(B, -1, 256), out_planes=True)
+            y = buf["yb16"]
+        else:
+            self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
         cur, r = y, 16
         for i in (3, 4, 6, 7, 9, 10):
             if i in (6, 9):
                 r *= 2
-                cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"])
+                cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"], out_planes=pl)
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
             nxt = {3: 4, 4: 6, 6: 7, 7: 9, 9: 10}.get(i)
             ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r),
-                            prefetch=W[f"{head}.c{nxt}_w"] if nxt else None)
+                            prefetch=W[f"{head}.c{nxt}_w"] if nxt else None, x_planes=pl)
             if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
                 ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
                                         W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"])
+            elif pl and i not in (4, 7):   # the next consumer is a conv: planes into the buffer that conv's input just vacated
+                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True, out=cur.view(B, -1, 256), out_planes=True)
+                dst = cur
             else:
                 self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True)
             cur = dst
@@ -376,8 +388,8 @@ class PoseNet(nn.Module):
             x = ops.convnext_stem(buf["roi_img"], W["stem.w"], W["stem.b"], W["stem.ln_w"], W["stem.ln_b"], buf["x0"])
         for s, (d, n) in enumerate(zip(dims, depths)):
             if s > 0:
-                t = ops.layernorm(x, W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"], buf[f"dsn{s}"])
-                x = ops.conv2d_nhwc(t, W[f"ds{s}.w"], 2, 2, 2, 0, out=buf[f"x{s}"], bias=W[f"ds{s}.b"])
+                t = ops.layernorm(x, W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"], buf[f"dsn{s}"], out_planes=self.split_gemm)
+                x = ops.conv2d_nhwc(t, W[f"ds{s}.w"], 2, 2, 2, 0, out=buf[f"x{s}"], bias=W[f"ds{s}.b"], x_planes=self.split_gemm)
             x2d = x.view(-1, d)
             for b in range(n):
                 q = f"s{s}b{b}."
@@ -388,7 +400,7 @@ class PoseNet(nn.Module):
                     ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
                              gamma=W[q + "gamma"], residual=x2d)
                     continue
-                t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7)
+                t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7, out_planes=self.split_gemm)
                 if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0:
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
                                      W[q + "gamma"], x2d, x2d)
@@ -398,7 +410,7 @@ class PoseNet(nn.Module):
                 # (split-operand mode: fc1 writes the hidden tensor as the fp16 planes fc2 reads -- no fp32 round trip, no split pass)
                 pl = self.split_gemm
                 ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU, prefetch=W[q + "fc2_w"],
-                         out_planes=pl)
+                         x_planes=pl, out_planes=pl)
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
                          gamma=W[q + "gamma"], residual=x2d, x_planes=pl,
                          prefetch=W.get(f"ds{s + 1}.w") if b == n - 1 else None)

@@ -25,6 +25,12 @@ extern "C" {
 
 enum gp_status { GP_OK = 0, GP_ERR_INVALID = -1, GP_ERR_LAUNCH = -2, GP_ERR_RUNTIME = -3 };
 enum gp_dtype { GP_F32 = 0, GP_F16 = 1, GP_F64 = 2 /* gp_dcnv3_forward_any / gp_dcnv3_backward only */ };
+/* OR-ed into `dtype` = GP_F32 of gp_dwconv_ln / gp_layernorm / gp_groupnorm_apply / gp_upsample_bilinear2x: the (dense) output is
+ * written as the two fp16 planes of the split-operand GEMM mode (hi at y, lo' = fp16((v - hi) * 2^GP_SPLIT_SHIFT) one tensor's
+ * worth of elements behind it, in y's fp32-sized storage) instead of fp32 -- the producer emits what gp_split_planes would make
+ * of its result, and the consumer is gp_gemm(split_shift = GP_SPLIT_SHIFT) reading X = y.  y must not alias x. */
+#define GP_OUT_PLANES 0x100
+#define GP_SPLIT_SHIFT 11
 enum gp_act { GP_ACT_NONE = 0, GP_ACT_GELU = 1, GP_ACT_RELU = 2, GP_ACT_LRELU = 3 /* slope 0.1 */ };
 /* GEMM epilogues: v = acc + bias; then */
 enum gp_epilogue {

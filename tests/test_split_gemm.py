@@ -216,3 +216,37 @@ def test_split_window_conv(B, H, Cin):
         else:
             assert rel64(out, F.gelu(ref)) < TOL
         outs[v] = out
+
+
+def test_producers_write_planes_like_gp_split_planes():
+    """dwconv_ln / layernorm / groupnorm_apply / upsample with out_planes: bit for bit the planes gp_split_planes makes of
+    their fp32 output (the split-operand GEMM that follows reads them with x_planes=True, no split pass in between)."""
+    o = ops()
+    dev = "cuda"
+    B, H, C = 2, 16, 256
+
+    def planes_of(t32):
+        return o.split_planes(t32.reshape(-1, t32.shape[-1]), t32.numel() // t32.shape[-1], t32.shape[-1], t32.shape[-1]).clone()[: 2 * t32.numel()]
+
+    x = rnd(B, H, H, C, seed=1).to(dev)
+    # dw7x7 + LN
+    wt, bias, lw, lb = rnd(49, C, seed=2).to(dev), rnd(C, seed=3).to(dev), rnd(C, seed=4).to(dev), rnd(C, seed=5).to(dev)
+    ref = o.dwconv_ln(x, wt, bias, lw, lb, torch.empty_like(x), 7)
+    got = o.dwconv_ln(x, wt, bias, lw, lb, torch.empty_like(x), 7, out_planes=True)
+    assert torch.equal(got.view(torch.float16).reshape(-1), planes_of(ref))
+    # row LayerNorm
+    ref = o.layernorm(x, lw, lb, torch.empty_like(x))
+    got = o.layernorm(x, lw, lb, torch.empty_like(x), out_planes=True)
+    assert torch.equal(got.view(torch.float16).reshape(-1), planes_of(ref))
+    # GroupNorm + GELU
+    part = torch.zeros(B * 64 * 32 * 2, device=dev)
+    xv = x.view(B, H * H, C)
+    ref = o.groupnorm(xv, lw, lb, torch.empty_like(xv), 32, o.ACT_GELU, part)
+    got = o.groupnorm(xv, lw, lb, torch.empty_like(xv), 32, o.ACT_GELU, part, out_planes=True)
+    assert torch.equal(got.view(torch.float16).reshape(-1), planes_of(ref))
+    with pytest.raises(RuntimeError):
+        o.groupnorm(xv, lw, lb, xv, 32, o.ACT_GELU, part, out_planes=True)        # in place is impossible: the planes overlap unread input
+    # bilinear x2
+    ref = o.upsample_bilinear2x(x, torch.empty(B, 2 * H, 2 * H, C, device=dev))
+    got = o.upsample_bilinear2x(x, torch.empty(B, 2 * H, 2 * H, C, device=dev), out_planes=True)
+    assert torch.equal(got.view(torch.float16).reshape(-1), planes_of(ref))
