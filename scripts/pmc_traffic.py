@@ -11,7 +11,7 @@ requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled 
 """
 import collections, csv, glob, json, sys
 
-CLASS = (("gemm", ("gemm_big_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
+CLASS = (("gemm", ("gemm_big_kernel", "gemm_wreg_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
          ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
          ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
          ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
@@ -43,7 +43,23 @@ for cls, _ in CLASS:
         res[cls] = {"launches_profiled": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb,
                     "hbm_bytes_per_launch": rd + wb, "hbm_bytes_per_step": (rd + wb) * n / steps}
 commit = sys.argv[5] if len(sys.argv) > 5 else "unknown"
+# optional 6th argument: scripts/pmc_calib.py's output -- FETCH_SIZE factors measured for this library's access shapes; the DCNv3
+# gather reads 128-byte rows with 16 lanes x 8 B, for which the x2 of the wide-stream rule need not hold
+calib = None
+if len(sys.argv) > 6:
+    try:
+        calib = json.load(open(sys.argv[6]))
+        f_rows = [v["factor_to_apply"] for k, v in calib.items() if "rows8" in k][0]
+        if "dcnv3" in res:
+            n = fe["dcnv3"][0]
+            rd = f_rows * fe["dcnv3"][1] * 1024 / n
+            wb = res["dcnv3"]["hbm_write_bytes_per_launch"]
+            res["dcnv3_calibrated"] = {"fetch_factor": f_rows, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wb,
+                                       "hbm_bytes_per_launch": rd + wb, "hbm_bytes_per_step": (rd + wb) * n / steps,
+                                       "note": "FETCH_SIZE factor measured by scripts/pmc_calib.hip for 128-byte rows read by 16 lanes x 8 B"}
+    except Exception as e:
+        calib = {"error": repr(e)}
 json.dump({"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-cpu-baseline --no-parity --no-h2d --inflight 1, bs=64 fp16",
-           "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "classes": res},
+           "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "calibration": calib, "classes": res},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

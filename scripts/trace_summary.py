@@ -5,7 +5,8 @@ path = sys.argv[1]
 f = glob.glob(path + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-stems = [i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"]]
+stems = [i for i, r in enumerate(rows) if "stem_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]]   # stem_kernel / stem_mfma_kernel / resnet_stem_kernel: first launch of a step
+assert len(stems) >= 2, "no two consecutive steps in the trace (no stem kernel found)"
 step = rows[stems[-2]:stems[-1]]
 agg = collections.OrderedDict()
 for r in step:
