@@ -1464,13 +1464,12 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // K = 512, >= 12288 rows, >= 1024 columns (stage-2 fc1 at bs 64): weights in registers (48.5 us against 51.4 for
             // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py); shorter M does not amortise the
             // 256 KB weight prologue per CU.  GP_GEMM_WREG=0: A/B switch
-            if (wreg_ok && !split && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
             // (split-operand mode: the K loop is three times as long, which is what the ping-pong tile's fill / drain is weighed
             // against; measured, scripts/split_variants.py: it wins from ~140 tiles of 256 x 256 up, below that the 128 x 128
             // two-workgroups-per-CU tile does; the 256 x 128 tile never)
-            const long keff = split ? 3l * d->K : d->K;
             if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
-            else if (d->N % 256 == 0 && keff >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
+            else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
         else variant = 4;
