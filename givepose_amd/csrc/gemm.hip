@@ -1360,6 +1360,11 @@ static bool wreg_enabled() {
     return on;
 }
 
+static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the ping-pong kernel when batches overlap (GP_GEMM_CO_MIN_TILES: A/B)
+    static const long k = [] { const char* e = getenv("GP_GEMM_CO_MIN_TILES"); return e ? atol(e) : 32l; }();
+    return k;
+}
+
 static long pp_min_tiles() {
     const char* e = getenv("GP_GEMM_PP_MIN_TILES");
     return e ? atol(e) : 192;
@@ -1469,7 +1474,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // two-workgroups-per-CU tile does; the 256 x 128 tile never)
             if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
             else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
-            else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= 32) || tA >= pp_min_tiles())) variant = 10;
+            else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= co_min_tiles()) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
         else variant = 4;
