@@ -23,7 +23,7 @@ struct DcnKP {
     const void* off;
     const void* mask;
     void* out;
-    int N, H, W, G, D, K, stride, pad, dil, rc, Ho, Wo, off_ld, mask_ld, logits;
+    int N, H, W, G, D, K, stride, pad, dil, rc, Ho, Wo, off_ld, mask_ld, logits, xcd;
     float os;
     long rows;  // N*Ho*Wo
 };
@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     const int t = lane & 15;
     if constexpr (PATCH) {
         const int ppr = p.Wo >> 2, ppi = ppr * (p.Ho >> 2);
-        const int pid = blockIdx.x;
+        // XCD x (workgroup ids equal mod 8 share one L2) owns a CONTIGUOUS run of patches: neighbouring patches read overlapping
+        // input footprints (stride 2, 3x3 taps, offsets of a few pixels: ~16 x 16 input pixels for 8 x 8 "owned" ones), and with
+        // the round-robin order each of them sat in a different L2 -- the halos then came from HBM / Infinity Cache once per XCD
+        // (PMC: 1.72 x the algorithmic bytes in round 2).  GP_DCN_XCD=0 keeps the old order (A/B).
+        const int pid = p.xcd ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
         b = pid / ppi;
         const int pin = pid - b * ppi;
         ho = (pin / ppr) * 4 + (threadIdx.x >> 6);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
         g = blockIdx.y;
         r = ((long)b * p.Ho + ho) * p.Wo + wo;
     } else {
-        r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        r = (long)(p.xcd ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + (threadIdx.x >> 6);
         if (r >= p.rows) return;  // whole wave exits together
         g = lane >> 4;
         wo = (int)(r % p.Wo);
@@ -283,6 +287,11 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     st4(reinterpret_cast<T*>(p.out) + r * 256 + cl * 4, acc);
 }
 
+static bool dcn_xcd_enabled() {   // GP_DCN_XCD=0: A/B switch for the XCD-contiguous workgroup order
+    static const bool on = [] { const char* e = getenv("GP_DCN_XCD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
     static const bool on = [] { const char* e = getenv("GP_DCN_PATCH"); return !(e && e[0] == '0'); }();
     return on;
@@ -328,6 +337,7 @@ extern "C" int gp_dcnv3_forward(const void* in, const void* offset, const void* 
     const int P = K * K - p.rc;
     GP_REQUIRE(off_ld >= G * P * 2 && mask_ld >= G * P, "gp_dcnv3_forward: off_ld/mask_ld too small");
     p.off_ld = off_ld; p.mask_ld = mask_ld; p.logits = mask_is_logits ? 1 : 0; p.os = offset_scale;
+    p.xcd = dcn_xcd_enabled() ? 1 : 0;
     p.rows = (long)N * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
     const int esz = dtype == GP_F16 ? 2 : 4, osz = om_dtype == GP_F16 ? 2 : 4;
