@@ -46,12 +46,18 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 class PoseNet(nn.Module):
     def __init__(self, cfg: PoseNetConfig = PoseNetConfig(), dtype=torch.float16, use_graph=False, seed=None, inflight=1,
-                 split_gemm=False):
+                 split_gemm=False, dcn_couple=None):
         """dtype: storage type of activations / weights (float16 = throughput mode, float32 = parity mode).
         split_gemm (float32 only): the dense contractions run on the fp16 matrix pipe with split operands (hi + 2^-11 lo'
         planes, three MFMAs per product, fp32 accumulate: gp_gemm_desc.split_shift) instead of the fp32 MFMA; everything
-        else is the float32 mode.  Error against the reference at the level of the fp32 mode (tests/precision_split.py)."""
+        else is the float32 mode.  Error against the reference at the level of the fp32 mode (tests/precision_split.py).
+        dcn_couple (grouped launches): a forward over B = G * dcn_couple crops is G independent batches of dcn_couple crops in
+        ONE launch sequence -- every kernel sees G times the rows, the weights pass through the chip once for all of them --
+        while the one thing that ties the crops of a batch together, the DCNv3 stride-2 offset / mask prefix (crop b reads
+        the rows of crop b // 4 OF ITS BATCH, SURVEY.md 0.3), stays per group: the results are bit for bit those of G
+        separate forwards (tests/test_hip_posenet.py::test_grouped_launch_equals_separate_batches)."""
         super().__init__()
+        self.dcn_couple = None if not dcn_couple else int(dcn_couple)
         if split_gemm and dtype != torch.float32:
             raise ValueError("split_gemm is a float32-storage mode")
         self.split_gemm = bool(split_gemm)
@@ -460,19 +466,31 @@ class PoseNet(nn.Module):
                     q = f"enc{weights_of}."
             if cfg.use_dcn == "dcnv3":
                 xin = buf[f"e_in{li}"]
-                nq = B * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
-                npre = min(B * r * r, nq + r + 8)   # + one image row of halo for the 3x3 depth-wise conv
+                # the full-resolution projection of every crop: one launch over all groups
                 if li == 0:
-                    ops.pointwise_k3(buf["nocs_nhwc4"][:npre], W[q + "conv_w"], W[q + "conv_b"], xin.view(-1, 256)[:npre])
                     ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "fold_w"], W[q + "fold_b"], buf[f"e_proj{li}"].view(-1, 256))
                 else:
-                    ops.gemm(prev.view(-1, 256)[:npre], W[q + "conv_w"], xin.view(-1, 256)[:npre], bias=W[q + "conv_b"])
                     ops.gemm(prev.view(-1, 256), W[q + "fold_w"], buf[f"e_proj{li}"].view(-1, 256), bias=W[q + "fold_b"])
-                ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"e_x1{li}"], 3,
-                              act=ACT_GELU, n_pixels=nq)
-                om = ops.gemm(buf[f"e_x1{li}"], W[q + "om_w"], buf[f"e_om{li}"], bias=W[q + "om_b"])
-                ops.dcnv3_forward_into(buf[f"e_proj{li}"], om, om[:, 72:], buf[f"e_g{li}"], 3, 2, 1, 1, 4, 64, 1.0,
-                                       off_ld=108, mask_ld=108, mask_is_logits=True)
+                # the offset / mask branch and the gather see ONE batch's flat prefix at a time (grouped launches: a group =
+                # one batch of dcn_couple crops; otherwise the whole forward is the one group)
+                Bg = self.dcn_couple if (self.dcn_couple and B > self.dcn_couple) else B
+                if B % Bg:
+                    raise ValueError(f"batch {B} is not a multiple of dcn_couple = {Bg}")
+                for g0 in range(0, B, Bg):
+                    gs = slice(g0, g0 + Bg)
+                    nq = Bg * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
+                    npre = min(Bg * r * r, nq + r + 8)   # + one image row of halo for the 3x3 depth-wise conv
+                    xin_g = xin[gs]
+                    if li == 0:
+                        ops.pointwise_k3(buf["nocs_nhwc4"][g0 * r * r:][:npre], W[q + "conv_w"], W[q + "conv_b"], xin_g.view(-1, 256)[:npre])
+                    else:
+                        ops.gemm(prev[gs].view(-1, 256)[:npre], W[q + "conv_w"], xin_g.view(-1, 256)[:npre], bias=W[q + "conv_b"])
+                    x1_g = buf[f"e_x1{li}"][g0 * r * r // 4:(g0 + Bg) * r * r // 4]
+                    om_g = buf[f"e_om{li}"][g0 * r * r // 4:(g0 + Bg) * r * r // 4]
+                    ops.dwconv_ln(xin_g, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], x1_g, 3, act=ACT_GELU, n_pixels=nq)
+                    ops.gemm(x1_g, W[q + "om_w"], om_g, bias=W[q + "om_b"])
+                    ops.dcnv3_forward_into(buf[f"e_proj{li}"][gs], om_g, om_g[:, 72:], buf[f"e_g{li}"][gs], 3, 2, 1, 1, 4, 64, 1.0,
+                                           off_ld=108, mask_ld=108, mask_is_logits=True)
                 y = buf[f"e_o{li}"]
                 ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"],
                          gn=self._gnarg(buf, ro * ro))

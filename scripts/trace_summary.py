@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) launches/avg/total of the LAST bench step."""
+"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) launches/avg/total of the LAST launch sequence of the run (from one
+stem kernel to the next: one batch, or the G batches of a grouped launch)."""
 import collections, csv, glob, sys
 path = sys.argv[1]
 f = glob.glob(path + "/**/*kernel_trace.csv", recursive=True)[0]

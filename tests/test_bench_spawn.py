@@ -39,4 +39,6 @@ def test_bench_two_ranks_without_torchrun():
     assert rc == 0, err
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0
-    assert line["overlap_check"] == {"slots": 2, "ranks": 2, "poses_bitwise_equal_to_serial_replay": True}
+    oc = line["overlap_check"]
+    assert oc["slots"] == 2 and oc["ranks"] == 2 and oc["batches_per_launch"] == 2 and oc["poses_bitwise_equal_to_serial_replay"] is True
+    assert line["config"]["batches_in_flight"] == 4
