@@ -167,6 +167,8 @@ def main():
                     help="put the host -> HBM transfer of every step's inputs INSIDE the timed step (pipelined on a copy stream); "
                          "the line then says so in config.inputs and is not the metric's `value` (inputs resident)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="profiling runs only: skip the overlap / grouping self-check (its extra forwards would be counted)")
+    ap.add_argument("--no-serial", action="store_true", help="profiling runs only: skip the serial legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f64", action="store_true", help="skip the float64 pass of the oracle (vs_float64: ~25 s of host time)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -271,7 +273,7 @@ def main():
     torch.cuda.synchronize(dev)
     over = [run.result(i).clone() for i in range(NF)]            # (world*BL, 15) with N > 1 (gathered), else (BL, 15)
     mine = [o[rank * BL:(rank + 1) * BL] if world > 1 else o for o in over]
-    if (NF > 1 or G > 1) and args.h2d != "frames":
+    if (NF > 1 or G > 1) and args.h2d != "frames" and not args.no_check:
         same = True
         for i in range(NF):
             o = net.forward_device(run.statics[i], dev, slot=i, wait=True)
@@ -320,7 +322,7 @@ def main():
         note(f"timed region: {value:.1f} images/s")
     # ---------------- the same K steps strictly one after the other, on a net BUILT for one batch in flight
     net1 = None
-    if NF > 1 or G > 1:
+    if (NF > 1 or G > 1) and not args.no_serial:
         net1 = PoseNet(cfg, seed=0, use_graph=not args.no_graph, inflight=1, **mode).to(dev)
         run1 = ShardRunner(net1, B, dev, world)
         run1.load(0, host)
@@ -330,7 +332,7 @@ def main():
         line["one_batch_in_flight"] = {"value": round(world * B * args.steps / dt1, 2), "unit": "images/s",
                                        "ms_per_step": round(dt1 / args.steps * 1e3, 4)}
     serial = net1 if net1 is not None else net
-    if G > 1:       # the launch sequence `value` runs, strictly one launch after the other: what the roofline leg times per kernel
+    if G > 1 and not args.no_serial:       # the launch sequence `value` runs, strictly one launch after the other: what the roofline leg times per kernel
         netg = PoseNet(cfg, seed=0, use_graph=not args.no_graph, inflight=1, dcn_couple=B, **mode).to(dev)
         rung = ShardRunner(netg, BL, dev, world)
         rung.load(0, batches[0])
@@ -397,7 +399,8 @@ def main():
         # committed profile of this workload and says which commit it was taken on
         pdir = os.path.join(ROOT, "profiles")
         pmc = sorted(p for p in os.listdir(pdir) if p.endswith("pmc_traffic.json")) if os.path.isdir(pdir) else []
-        if pmc and args.batch == 64 and args.dtype == "f16" and args.workload == "full" and G == 1:
+        pmc = [f for f in pmc if json.load(open(os.path.join(pdir, f))).get("batches_per_launch", 1) == G]   # (a profile of the same launch shape)
+        if pmc and args.batch == 64 and args.dtype == "f16" and args.workload == "full":
             tj = json.load(open(os.path.join(pdir, pmc[-1])))
             t = tj["classes"]
             line["roofline"]["traffic"] = round(t["gemm"]["hbm_bytes_per_step"] / g["launches_per_step"])

@@ -26,16 +26,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_inflight -- python
 step "[3] kernel trace, split-operand mode (serial eager)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_split -- python3 bench.py --dtype split --steps 6 --warmup 3 --group 1 --inflight 1 --no-graph --no-roofline $A > $O/bench_kt_split.json 2> $O/bench_kt_split.err || { step "kt_split failed"; tail -5 $O/bench_kt_split.err; exit 1; }
 python3 scripts/trace_summary.py $O/kt_split > $O/step_kernels_split.txt 2>&1 || true
-step "[4] PMC FETCH_SIZE"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-roofline --group 1 --inflight 1 $A > $O/bench_f.json 2> $O/bench_f.err || { step "fetch failed"; tail -5 $O/bench_f.err; exit 1; }
+P="--steps 4 --warmup 1 --no-graph --no-roofline --group 2 --inflight 1 --no-check --no-serial $A"     # 4 launches of 2 batches = 8 batches profiled
+step "[4] PMC FETCH_SIZE (the benched launch sequence: 2 batches per launch)"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 bench.py $P > $O/bench_f.json 2> $O/bench_f.err || { step "fetch failed"; tail -5 $O/bench_f.err; exit 1; }
 step "[5] PMC WRITE_SIZE"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-roofline --group 1 --inflight 1 $A > $O/bench_w.json 2> $O/bench_w.err || { step "write failed"; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 bench.py $P > $O/bench_w.json 2> $O/bench_w.err || { step "write failed"; exit 1; }
 step "[6] FETCH_SIZE calibration (16 B / lane stream, 8 B / lane stream, 128-byte rows by 16 lanes x 8 B)"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value scripts/pmc_calib.hip -o /tmp/pmc_calib && \
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/calib -- /tmp/pmc_calib > $O/calib.out 2>&1 && python3 scripts/pmc_calib.py $O/calib > $O/pmc_calib.json 2>&1 || step "calibration failed"
-python3 scripts/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json 4 $GP_COMMIT $O/pmc_calib.json > $O/pmc_traffic.txt 2>&1 || true
+python3 scripts/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json 8 $GP_COMMIT $O/pmc_calib.json 2 > $O/pmc_traffic.txt 2>&1 || true
 step "[7] PMC MFMA busy"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-roofline --group 1 --inflight 1 $A > $O/bench_s.json 2> $O/bench_s.err || { step "sq failed"; exit 1; }
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/sq -- python3 bench.py $P > $O/bench_s.json 2> $O/bench_s.err || { step "sq failed"; exit 1; }
 python3 scripts/mfma_busy.py $O/sq > $O/mfma_busy.txt 2>&1 || true
 step "[8] DCNv3 gather: PATCH mapping on / off"
 ( echo "GP_DCN_PATCH=1 (default: 4x4 output patch of one group per workgroup)"; GP_DCN_PATCH=1 python3 scripts/dcn_bench.py; echo "GP_DCN_PATCH=0 (wave per output pixel, all four groups)"; GP_DCN_PATCH=0 python3 scripts/dcn_bench.py ) > $O/dcn_patch_ab.txt 2>&1 || true
