@@ -363,8 +363,12 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 // ---- generic epilogue of the tile kernels (any output type, edge tiles, split-operand mode), through a wave-private LDS
 //      slab (8 KB).  RT = element type of residual and output (fp32 in the split-operand mode); mb / nb = first row / column
 //      of the WAVE's tile.
-template <typename RT, int MT, int NT, bool SPL>
-__device__ __forceinline__ void epilogue_generic(const GemmKP& p, f32x4 (&acc)[NT][MT], char* slab, int mb, int nb, int lane) {
+// EPI_CT >= 0: the epilogue code is known at compile time (the split-operand kernels dispatch on it once per workgroup: the
+// run-time switch around every 4-element group costs more than the arithmetic, section 5.1 of DESIGN.md); -1: read p.epi.
+template <typename RT, int MT, int NT, bool SPL, int EPI_CT = -1>
+__device__ __forceinline__ void epilogue_generic(const GemmKP& pin, f32x4 (&acc)[NT][MT], char* slab, int mb, int nb, int lane) {
+    const GemmKP& p = pin;
+    const int epi_code = EPI_CT >= 0 ? EPI_CT : pin.epi;
     // ---- epilogue through a wave-private LDS slab: 32 rows (m) x 64 fp32 (n), 16-B chunk ^= row & 7.
     //      Lane owns output columns n .. n+3 (fixed) of rows i*4 + (lane>>4); every global load (bias, gamma,
     //      the whole residual tile in f16 mode) is issued before the first store.
@@ -373,8 +377,8 @@ __device__ __forceinline__ void epilogue_generic(const GemmKP& p, f32x4 (&acc)[N
     const bool nok = en < p.N;
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 b4 = (p.bias && nok) ? *reinterpret_cast<const f32x4*>(p.bias + en) : zero4;
-    const bool sres = p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU;
-    const f32x4 g4 = (p.epi == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
+    const bool sres = epi_code == GP_EPI_SCALE_RES || epi_code == GP_EPI_RES_RELU;
+    const f32x4 g4 = (epi_code == GP_EPI_SCALE_RES && nok) ? *reinterpret_cast<const f32x4*>(p.gamma + en) : zero4;
     constexpr bool PRE = sizeof(RT) == 2;           // f16: prefetch the whole residual tile (64 VGPRs at MT = 8)
     typename Res4<RT>::type r4[PRE ? MT / 2 : 1][8];
     if (PRE) {
@@ -413,7 +417,7 @@ __device__ __forceinline__ void epilogue_generic(const GemmKP& p, f32x4 (&acc)[N
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 256 + ((chunk ^ (row & 7)) << 4));
                 const int m = mb + j * 32 + row;
                 if (m < p.M && nok) {
-                    const f32x4 o = epi_apply<RT>(p.epi, v, b4, g4, r4[PRE ? j : 0][i]);
+                    const f32x4 o = epi_apply<RT>(epi_code, v, b4, g4, r4[PRE ? j : 0][i]);
                     if (SPL && p.out_planes) {   // hi = fp16(o), lo' = fp16((o - hi) 2^S): what gp_split_planes would make of the fp32 result
                         half4 hv, lv;
 #pragma unroll
@@ -447,6 +451,18 @@ __device__ __forceinline__ void epilogue_generic(const GemmKP& p, f32x4 (&acc)[N
             }
             gsum = gsq = 0.f;
         }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_split(const GemmKP& p, f32x4 (&acc)[NT][MT], char* slab, int mb, int nb, int lane) {
+    switch (p.epi) {       // wave-uniform, once per workgroup
+        case GP_EPI_GELU: epilogue_generic<float, MT, NT, true, GP_EPI_GELU>(p, acc, slab, mb, nb, lane); break;
+        case GP_EPI_RELU: epilogue_generic<float, MT, NT, true, GP_EPI_RELU>(p, acc, slab, mb, nb, lane); break;
+        case GP_EPI_LRELU: epilogue_generic<float, MT, NT, true, GP_EPI_LRELU>(p, acc, slab, mb, nb, lane); break;
+        case GP_EPI_SCALE_RES: epilogue_generic<float, MT, NT, true, GP_EPI_SCALE_RES>(p, acc, slab, mb, nb, lane); break;
+        case GP_EPI_RES_RELU: epilogue_generic<float, MT, NT, true, GP_EPI_RES_RELU>(p, acc, slab, mb, nb, lane); break;
+        default: epilogue_generic<float, MT, NT, true, GP_EPI_NONE>(p, acc, slab, mb, nb, lane); break;
     }
 }
 
@@ -851,7 +867,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             return;
         }
     }
-    epilogue_generic<RT, MT, NT, SPL>(p, acc, smem + wave * 8192, m0 + wm * MT * 16, n0 + wn * NT * 16, lane);
+    if constexpr (SPL) epilogue_split<MT, NT>(p, acc, smem + wave * 8192, m0 + wm * MT * 16, n0 + wn * NT * 16, lane);
+    else epilogue_generic<RT, MT, NT, SPL>(p, acc, smem + wave * 8192, m0 + wm * MT * 16, n0 + wn * NT * 16, lane);
 }
 
 // =====================================================================================================
@@ -1066,7 +1083,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 
     const int mb = m0 + wm * 128, nb = wn * 64;
     if constexpr (SPL) {
-        epilogue_generic<float, MT, NT, true>(p, acc, smem + wave * 8192, mb, nb, lane);
+        epilogue_split<MT, NT>(p, acc, smem + wave * 8192, mb, nb, lane);
     } else {
         char* slab = smem + wave * 9216;
         switch (p.epi) {
