@@ -42,3 +42,19 @@ def test_bench_two_ranks_without_torchrun():
     oc = line["overlap_check"]
     assert oc["slots"] == 2 and oc["ranks"] == 2 and oc["batches_per_launch"] == 2 and oc["poses_bitwise_equal_to_serial_replay"] is True
     assert line["config"]["batches_in_flight"] == 4
+
+
+def test_bench_helpers_on_cpu():
+    """err_stats (the measured vs_reference object) and the subprocess-free commit id."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    ref = torch.zeros(10, 15)
+    got = ref.clone()
+    got[3, 4] = 2e-4            # one crop's R off by 2e-4
+    got[:, 9] = 5e-6            # every t by 5e-6
+    e = bench.err_stats(got, ref)
+    assert abs(e["rot"] - 2e-4) < 1e-9 and e["rot_median_over_crops"] == 0.0 and abs(e["trans"] - 5e-6) < 1e-9 and e["size"] == 0.0
+    assert e["meets_1e-4"] is False and bench.err_stats(ref + 5e-5, ref)["meets_1e-4"] is True
+    c = bench.git_head()
+    assert c is None or (len(c) == 7 and all(ch in "0123456789abcdef" for ch in c))
