@@ -378,3 +378,28 @@ def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
     assert m("gemm v10 M16384 N2048 K512 epi1 split3") == 27 and m("gemm v7 M16384 N512 K2048 epi4 split3") == 27, sp
     assert m("conv3x3 s1 v13 64x64 Cin256 Cout256 M262144 +gn split3") == 4, sp
     assert m("split_planes") <= 30, sp          # only the small tensors still take a split pass
+
+
+def test_grouped_launches_in_flight_bs128_stress():
+    """The bench default: two launch sequences of 2 x 64 crops in flight; every buffer the path writes checked bitwise against
+    the serial run of the same slot, 15 repetitions."""
+    from givepose_amd import PoseNet, PoseNetConfig, synth
+    B, NS = 128, 2
+    net = PoseNet(PoseNetConfig(), dtype=torch.float16, seed=0, use_graph=True, inflight=NS, dcn_couple=64).cuda()
+    dev = torch.device("cuda")
+    d = [{k: torch.from_numpy(v).cuda() for k, v in synth.synth_batch(B, seed=51 + i).items()} for i in range(NS)]
+    unwritten = ("h0", "h1", "e_in0", "e_in1", "e_in2")                  # scratch the default wiring never fills completely
+    ref = []
+    for i in range(NS):
+        for _ in range(3):
+            net.forward_device(d[i], slot=i)
+        torch.cuda.synchronize()
+        ref.append({k: v.clone() for k, v in net._plan(B, dev, i)["buf"].items() if k not in unwritten})
+    for rep in range(15):
+        for i in range(NS):
+            net.forward_device(d[i], slot=i, wait=False)
+        torch.cuda.synchronize()
+        for i in range(NS):
+            buf = net._plan(B, dev, i)["buf"]
+            bad = [k for k, r in ref[i].items() if not torch.equal(buf[k], r)]
+            assert not bad, (rep, i, bad)
