@@ -403,11 +403,11 @@ def main():
         if pmc and args.batch == 64 and args.dtype == "f16" and args.workload == "full":
             tj = json.load(open(os.path.join(pdir, pmc[-1])))
             t = tj["classes"]
-            line["roofline"]["traffic"] = round(t["gemm"]["hbm_bytes_per_step"] / g["launches_per_step"])
+            line["roofline"]["traffic"] = round(t["gemm"]["hbm_bytes_per_launch"])       # class average per launch of the same launch shape, like `achieved`
             line["roofline"]["traffic_source"] = {"file": "profiles/" + pmc[-1], "commit": tj.get("commit", "unknown (round 1)"),
                                                   "unit": "HBM bytes per launch, class average"}
             if "dcnv3" in classes and "dcnv3" in t:
-                line["roofline_gather"]["traffic"] = round(t["dcnv3"]["hbm_bytes_per_step"] / classes["dcnv3"]["launches_per_step"])
+                line["roofline_gather"]["traffic"] = round(t["dcnv3"]["hbm_bytes_per_launch"])
         line["kernel_classes"] = classes
         line["kernels_top8"] = top[:8]
         if args.kernels_out:
@@ -421,9 +421,14 @@ def main():
     parity_out = {}
     if rank == 0 and world == 1 and not args.no_parity and args.dtype == "f16":      # N = 1 only: the other ranks of an N > 1 run wait in the final barrier
         fast = mine[0][:B]
-        for key, kw, what in (("parity_mode", MODES["split"], "fp32 storage, dense contractions as split-operand fp16 MFMA (hi + 2^-11 lo' planes, 3 MFMAs, fp32 accumulate)"),
-                              ("parity_mode_fp32_mfma", MODES["f32"], "fp32 storage, fp32 MFMA")):
-            netp = PoseNet(cfg, seed=0, use_graph=not args.no_graph, inflight=NF, **kw).to(dev)
+        import dataclasses
+        legs = [("parity_mode", MODES["split"], "fp32 storage, dense contractions as split-operand fp16 MFMA (hi + 2^-11 lo' planes, 3 MFMAs, fp32 accumulate)", cfg),
+                ("parity_mode_fp32_mfma", MODES["f32"], "fp32 storage, fp32 MFMA", cfg)]
+        if cfg.main_backbone == "convnext":
+            legs.append(("fp16_fp32_residual_stream", MODES["f16"], "fp16 storage with the residual stream of ConvNeXt stage 2 (27 of 36 blocks) accumulated "
+                         "in fp32 (PoseNetConfig.res_fp32): the mitigation the reviews asked for, measured", dataclasses.replace(cfg, res_fp32=True)))
+        for key, kw, what, cfgp in legs:
+            netp = PoseNet(cfgp, seed=0, use_graph=not args.no_graph, inflight=NF, **kw).to(dev)
             rp = ShardRunner(netp, B, dev, 1, inflight=NF)
             for i in range(NF):
                 rp.load(i, singles[i * G])
@@ -446,6 +451,7 @@ def main():
                          "overlap_bitwise_equal_to_serial_replay": bool(same_p), "vs_reference": None,
                          "path_roofline_frac_mfma" + ("_f32" if key.endswith("mfma") else "_f16_algorithmic"):
                              round(B * n_p / pdt * GFLOP_PER_CROP[args.workload] * 1e9 / ((PEAK_F32_TFLOPS if key.endswith("mfma") else PEAK_F16_TFLOPS) * 1e12), 4),
+                         "batches_in_flight": NF,
                          "fast_vs_parity_max_abs": {"rot": float(dd[:, :9].max()), "trans": float(dd[:, 9:12].max()), "size": float(dd[:, 12:].max())}}
             del rp
             del netp

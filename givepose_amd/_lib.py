@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
-ABI_VERSION = 300        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
+ABI_VERSION = 310        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
 GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
@@ -30,7 +30,8 @@ class GemmDesc(Structure):
                 ("ln_stats", c_void_p), ("ln_colsum", c_void_p), ("ln_nslab", c_int), ("ln_eps", c_float),
                 ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long),
                 ("split_shift", c_int), ("x_plane_stride", c_long), ("w_plane_stride", c_long),
-                ("out_planes", c_int), ("c_plane_stride", c_long)]
+                ("out_planes", c_int), ("c_plane_stride", c_long),
+                ("residual_f32", c_int), ("c16", c_void_p), ("ldc16", c_int)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)

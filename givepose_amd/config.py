@@ -33,6 +33,11 @@ class PoseNetConfig:
     # (bs 64): depth-wise 25.2 -> 22.9 us but fc1 52 -> 58 us per block, a net loss, hence off by default.
     defer_ln: bool = False
 
+    # build-side switch (fp16 storage only): the residual stream of stage 2 (27 of the 36 ConvNeXt blocks) is accumulated in
+    # fp32 -- the downsample conv and every fc2 epilogue write it in fp32 plus an fp16 copy for the depth-wise conv -- so that
+    # the fp16 rounding of the stream is not compounded block after block.  Measured: DESIGN.md 5c.
+    res_fp32: bool = False
+
     @property
     def feature_channel(self) -> int:
         return {"convnext": self.convnext_dims[-1], "resnet34": 512}[self.main_backbone]

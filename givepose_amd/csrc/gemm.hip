@@ -51,6 +51,10 @@ struct GemmKP {
     int out_planes;
     long cplane;
     float split_up;   // 2^S
+    // gp_gemm_desc.c16: besides the fp32 output C, the same values rounded to fp16 at c16 (row stride ldc16) -- the fp32 residual
+    // stream of the fp16 mode: the stream is accumulated in fp32, the next block's depth-wise conv reads the rounded copy
+    void* c16;
+    int ldc16;
 };
 
 template <typename T>
@@ -430,6 +434,12 @@ __device__ __forceinline__ void epilogue_generic(const GemmKP& pin, f32x4 (&acc)
                         *reinterpret_cast<half4*>(ch + p.cplane) = lv;
                     } else
                     if (p.dbg != 4 || o[0] == 12345.678f) store4<RT>(p, m, en, o);
+                    if (p.c16) {
+                        half4 hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)o[e];
+                        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.c16) + (long)m * p.ldc16 + en) = hv;
+                    }
                     gsum += (o[0] + o[1]) + (o[2] + o[3]);
                     gsq += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
                 }
@@ -466,11 +476,12 @@ __device__ __forceinline__ void epilogue_split(const GemmKP& p, f32x4 (&acc)[NT]
     }
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false>
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false, bool R32 = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_kernel(const GemmKP pin) {
     static_assert(NT == 4, "epilogue slab assumes a 64-wide wave tile");
     static_assert(!SPL || sizeof(T) == 2, "split-operand mode: fp16 planes");
-    typedef typename std::conditional<SPL, float, T>::type RT;   // residual / output element (SPL: always fp32)
+    static_assert(!R32 || (sizeof(T) == 2 && !SPL), "R32: fp16 operands with an fp32 residual / output");
+    typedef typename std::conditional<SPL || R32, float, T>::type RT;   // residual / output element (SPL, R32: fp32)
     // split-K (generic ring schedule only): workgroup row blockIdx.y multiplies K steps [kt0, kt0 + nkt) into its own
     // fp32 slab of the workspace; the host passes C = workspace, out_f32, no bias / epilogue (splitk_reduce_kernel applies them)
     GemmKP p = pin;
@@ -1321,7 +1332,7 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     stores(T - 1);
 }
 
-template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false> void launch_big(GemmKP& p, hipStream_t s) {
+template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false, bool R32 = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
     if constexpr (SPL) { p.split_n1 = p.nkt; p.nkt *= 3; }   // three K segments (GemmKP::split_n1)
@@ -1336,7 +1347,7 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
             splits = p.splitk;
         }
     }
-    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP, SPL>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
+    hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP, SPL, R32>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
 }
 
 }  // namespace
@@ -1418,6 +1429,14 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     p.epi = d->epilogue; p.out_f32 = d->out_f32;
     p.ln_stats = d->ln_stats; p.ln_s = d->ln_colsum; p.ln_nsl = d->ln_nslab; p.ln_eps = d->ln_eps;
     if (d->prefetch && d->prefetch_bytes > 0 && prefetch_enabled()) { p.pf = reinterpret_cast<const char*>(d->prefetch); p.pf_bytes = d->prefetch_bytes; }
+    const bool r32 = d->residual_f32 != 0;       // fp16 operands, fp32 residual (and output): the fp32 residual stream of the fp16 mode
+    if (r32) GP_REQUIRE(d->dtype == GP_F16 && d->out_f32 && d->split_shift == 0 && d->splitk <= 1 && d->residual,
+                        "gp_gemm: residual_f32 needs dtype GP_F16, out_f32, a residual, no split-K");
+    if (d->c16) {
+        GP_REQUIRE(d->out_f32 && d->dtype == GP_F16 && d->splitk <= 1 && d->ldc16 >= d->N && d->ldc16 % 4 == 0 && !d->out_planes,
+                   "gp_gemm: c16 (fp16 copy of an fp32 output) needs dtype GP_F16, out_f32, ldc16 >= N, no split-K");
+        p.c16 = d->c16; p.ldc16 = d->ldc16;
+    }
     const bool split = d->split_shift > 0;
     if (split) {   // split-operand mode: fp16 hi / lo' planes in, fp32 out (GemmKP::split_n1)
         GP_REQUIRE(d->dtype == GP_F16 && d->out_f32, "gp_gemm: split-operand mode takes fp16 planes (dtype GP_F16) and writes fp32 (out_f32)");
@@ -1496,6 +1515,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         }
         else variant = 4;
     }
+    if (r32 && d->variant % 100 == 0 && variant != 10) variant = 7;
     // 3x3 s1 p1, Cout 256, whole image rows per 256-pixel tile: the LDS-window kernel (variant 13; automatic when the
     // ping-pong kernel would have been chosen)
     const bool win_ok = d->dtype == GP_F16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->N == 256 &&
@@ -1505,6 +1525,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
     GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
+    GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 16) {
@@ -1549,6 +1570,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     }
     if (variant == 10) {   // 256x256 ping-pong: 8 waves of 128x64, 64-byte K steps, 4-stage ring, one workgroup per CU
         if (split) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true, true>(p, s);
+        else if (r32) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true, false, true>(p, s);
         else if (d->dtype == GP_F16) launch_big<half_t, 2, 4, 8, 4, 4, false, 64, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }
@@ -1568,6 +1590,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     }
     if (variant == 7) {
         if (split) launch_big<half_t, 2, 2, 4, 4, 2, true, 128, false, true>(p, s);
+        else if (r32) launch_big<half_t, 2, 2, 4, 4, 2, true, 128, false, false, true>(p, s);
         else if (d->dtype == GP_F16) launch_big<half_t, 2, 2, 4, 4, 2, true>(p, s); else launch_big<float, 2, 2, 4, 4, 2>(p, s);
         GP_LAUNCH_CHECK("gp_gemm");
     }

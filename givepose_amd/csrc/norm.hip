@@ -615,8 +615,10 @@ void launch_dw7_raw(const void* x, const void* wt, const float* bias, void* y, f
 }
 
 // ---------------------------------------------------------------------------- row LayerNorm
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ w,
+// TI != T: fp32 input rows, fp16 output (dtype GP_F16 | GP_IN_F32: the fp32 residual stream of the fp16 mode enters the
+// downsample LayerNorm in fp32); a thread then loads its 8 elements as two 16-byte vectors
+template <typename T, typename TI = T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ y,
                                                         long rows, int C, float eps, int ldy, long pl) {
     constexpr int VEC = Vec16<T>::N;
@@ -627,9 +629,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const bool valid = row < rows;
     float a[VEC];
     if (valid) {
-        const Vec16<T> v = load16<T>(x + row * C + cs * VEC);
+        if constexpr (std::is_same<T, TI>::value) {
+            const Vec16<T> v = load16<T>(x + row * C + cs * VEC);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) a[e] = v.get(e);
+            for (int e = 0; e < VEC; ++e) a[e] = v.get(e);
+        } else {
+            static_assert(sizeof(TI) == 4 && VEC == 8, "mixed form: fp32 in, fp16 out");
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + row * C + cs * VEC), v1 = *reinterpret_cast<const f32x4*>(x + row * C + cs * VEC + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = v0[e]; a[e + 4] = v1[e]; }
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) a[e] = 0.f;
@@ -1079,16 +1088,19 @@ extern "C" int gp_layernorm(const void* x, const float* w, const float* b, void*
                             int ldy, int dtype_in, void* stream) {
     if (ldy <= 0) ldy = C;
     GP_REQUIRE(x && w && b && y && rows > 0, "gp_layernorm: bad argument");
-    const int dtype = dtype_in & ~GP_OUT_PLANES;
+    const int dtype = dtype_in & ~(GP_OUT_PLANES | GP_IN_F32);
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_layernorm: bad dtype");
     GP_REQUIRE(!(dtype_in & GP_OUT_PLANES) || (dtype == GP_F32 && x != y && ldy == C), "gp_layernorm: GP_OUT_PLANES needs GP_F32, y != x and a dense output");
+    GP_REQUIRE(!(dtype_in & GP_IN_F32) || (dtype == GP_F16 && x != y), "gp_layernorm: GP_IN_F32 (fp32 input rows) goes with GP_F16 output, y != x");
     const long pl = (dtype_in & GP_OUT_PLANES) ? rows * C : 0;
     const int esz = dtype == GP_F16 ? 2 : 4;
     GP_REQUIRE(ct_ok(C, esz), "gp_layernorm: unsupported C=%d", C);
     const int CT = C / (16 / esz), PG = 256 / CT;
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_NORM, 8.0 * rows * C, (double)rows * C * esz * 2);
-    if (dtype == GP_F16)
+    if (dtype == GP_F16 && (dtype_in & GP_IN_F32))
+        hipLaunchKernelGGL((layernorm_kernel<half_t, float>), dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (half_t*)y, rows, C, eps, ldy, 0l);
+    else if (dtype == GP_F16)
         hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const half_t*)x, w, b, (half_t*)y, rows, C, eps, ldy, 0l);
     else
         hipLaunchKernelGGL(layernorm_kernel<float>, dim3(cdiv(rows, PG)), dim3(256), 0, s, (const float*)x, w, b, (float*)y, rows, C, eps, ldy, pl);

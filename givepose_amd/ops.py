@@ -154,12 +154,14 @@ def auto_splitk(M, N, K, esz, n_cu=256):
 
 def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=None, K=None, ldx=None, ldc=None,
          ldres=None, conv=None, splitk=None, variant=0, gn=None, ln=None, prefetch=None, _stamps=None, x_planes=False,
-         out_planes=False):
+         out_planes=False, out16=None):
     """out[m][n] = epi(sum_k x[m][k] w[n][k] + bias[n]).  ``x``/``w`` share dtype (f16|f32); ``out`` is that
     dtype or float32.  conv = dict(B,H,W,Cin,KH,KW,stride,pad) switches X to channels-last implicit GEMM.
     prefetch = a tensor (the weights of the NEXT launch on this stream) to be pulled towards the caches meanwhile: a hint.
     w a SplitW: split-operand mode (fp32 x / out, fp16 hi + lo' operand planes).  out_planes: `out` (fp32 (M, N) storage) receives
-    the result as the two fp16 planes [hi (M, N) | lo' (M, N)] instead of fp32 values; x_planes: `x` is such a container."""
+    the result as the two fp16 planes [hi (M, N) | lo' (M, N)] instead of fp32 values; x_planes: `x` is such a container.
+    fp16 x / w with a float32 `residual` and float32 `out`: the fp32 residual stream of the fp16 mode (gp_gemm_desc.residual_f32);
+    out16: a float16 tensor that receives the same output values rounded (gp_gemm_desc.c16), for the consumers that read fp16."""
     split = isinstance(w, SplitW)
     dt = x.dtype
     if split:
@@ -228,6 +230,16 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
         d.workspace = _stamps.data_ptr()
     d.M, d.N, d.K, d.ldx, d.ldc = M, N, K, ldx, ldc
     d.ldres = (residual.stride(0) if ldres is None else ldres) if residual is not None else 0
+    if not split and residual is not None and residual.dtype == torch.float32 and dt == torch.float16:
+        if out.dtype != torch.float32:
+            raise TypeError("gemm: an fp32 residual goes with an fp32 output")
+        d.residual_f32 = 1
+        splitk = 1
+    if out16 is not None:
+        if out16.dtype != torch.float16 or out.dtype != torch.float32 or dt != torch.float16 or split:
+            raise TypeError("gemm(out16): fp16 operands, float32 out, float16 out16")
+        d.c16, d.ldc16 = out16.data_ptr(), out16.stride(0)
+        splitk = 1
     d.epilogue, d.out_f32, d.splitk, d.dtype, d.variant = epilogue, out_f32, splitk, code, variant
     d.co_scheduled = 1 if CO_SCHEDULED else 0
     if prefetch is not None:
@@ -241,7 +253,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
 
 
 def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=EPI_NONE, variant=0, gn=None,
-                residual=None, prefetch=None, x_planes=False):
+                residual=None, prefetch=None, x_planes=False, out16=None):
     """Channels-last convolution: x (B,H,W,Cin), w_packed (Cout, KH*KW*Cin) with K = (kh*KW+kw)*Cin+ci."""
     B, H, W_, Cin = x.shape
     Ho = (H + 2 * pad - KH) // stride + 1
@@ -251,7 +263,7 @@ def conv2d_nhwc(x, w_packed, KH, KW, stride, pad, out=None, bias=None, epilogue=
     gemm(x, w_packed, out.view(B * Ho * Wo, -1), bias=bias, epilogue=epilogue,
          residual=None if residual is None else residual.view(B * Ho * Wo, -1),
          conv=dict(B=B, H=H, W=W_, Cin=Cin, KH=KH, KW=KW, stride=stride, pad=pad), variant=variant, gn=gn, prefetch=prefetch,
-         x_planes=x_planes)
+         x_planes=x_planes, out16=None if out16 is None else out16.view(B * Ho * Wo, -1))
     return out
 
 
@@ -398,11 +410,17 @@ def dwconv7_raw_stats(x, wt, bias, out, stats):
     return out
 
 
+IN_F32 = 0x200         # include/givepose_hip.h GP_IN_F32
+
+
 def layernorm(x, w, b, out, eps=1e-6, ldy=0, out_planes=False):
     C = x.shape[-1]
     rows = x.numel() // C
-    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, ldy, _planes_code(x, out_planes, out), _stream()),
-          "gp_layernorm")
+    if x.dtype == torch.float32 and out.dtype == torch.float16:        # fp32 residual stream of the fp16 mode -> fp16 branch
+        code = GP_F16 | IN_F32
+    else:
+        code = _planes_code(x, out_planes, out)
+    check(_L().gp_layernorm(_ptr(_contig(x, "x")), _ptr(w), _ptr(b), _ptr(out), rows, C, eps, ldy, code, _stream()), "gp_layernorm")
     return out
 
 

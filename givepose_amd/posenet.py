@@ -65,6 +65,8 @@ class PoseNet(nn.Module):
         # defined but never wired there) is this build's throughput variant with feature_channel 512
         if cfg.main_backbone not in ("convnext", "resnet34"):
             raise NotImplementedError(f"unknown backbone {cfg.main_backbone}")
+        if cfg.res_fp32 and (dtype != torch.float16 or cfg.defer_ln or cfg.main_backbone != "convnext"):
+            raise ValueError("res_fp32 is an option of the float16 ConvNeXt path (without defer_ln)")
         self.cfg = cfg
         self.compute_dtype = dtype
         self.use_graph = use_graph
@@ -275,7 +277,10 @@ class PoseNet(nn.Module):
                     buf[f"rs{li}{n}"] = e(B, h, h, planes)
         for s, d in enumerate(dims):
             h = H >> s
-            buf[f"x{s}"] = e(B, h, h, d)
+            if cfg.res_fp32 and T == torch.float16 and d == 512:     # fp32 residual stream (+ the fp16 copy the branch reads)
+                buf[f"x{s}"], buf[f"x{s}h"] = f(B, h, h, d), e(B, h, h, d)
+            else:
+                buf[f"x{s}"] = e(B, h, h, d)
             buf[f"t{s}"] = e(B, h, h, d)
             buf[f"h{s}"] = e(B * h * h, 4 * d)
             if d == 512:
@@ -395,8 +400,11 @@ class PoseNet(nn.Module):
         for s, (d, n) in enumerate(zip(dims, depths)):
             if s > 0:
                 t = ops.layernorm(x, W[f"ds{s}.ln_w"], W[f"ds{s}.ln_b"], buf[f"dsn{s}"], out_planes=self.split_gemm)
-                x = ops.conv2d_nhwc(t, W[f"ds{s}.w"], 2, 2, 2, 0, out=buf[f"x{s}"], bias=W[f"ds{s}.b"], x_planes=self.split_gemm)
+                x = ops.conv2d_nhwc(t, W[f"ds{s}.w"], 2, 2, 2, 0, out=buf[f"x{s}"], bias=W[f"ds{s}.b"], x_planes=self.split_gemm,
+                                    out16=buf.get(f"x{s}h"))
             x2d = x.view(-1, d)
+            xh = buf.get(f"x{s}h")          # fp32 residual stream (cfg.res_fp32): x is fp32, the branch reads this fp16 copy
+            xin = x if xh is None else xh
             for b in range(n):
                 q = f"s{s}b{b}."
                 if (q + "fc1_wg") in W and x2d.shape[0] % 256 == 0 and x.shape[1] % 4 == 0 and x.shape[2] % 16 == 0:
@@ -406,7 +414,7 @@ class PoseNet(nn.Module):
                     ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
                              gamma=W[q + "gamma"], residual=x2d)
                     continue
-                t = ops.dwconv_ln(x, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7, out_planes=self.split_gemm)
+                t = ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7, out_planes=self.split_gemm)
                 if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0:
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
                                      W[q + "gamma"], x2d, x2d)
@@ -418,7 +426,7 @@ class PoseNet(nn.Module):
                 ops.gemm(t.view(-1, d), W[q + "fc1_w"], buf[f"h{s}"], bias=W[q + "fc1_b"], epilogue=EPI_GELU, prefetch=W[q + "fc2_w"],
                          x_planes=pl, out_planes=pl)
                 ops.gemm(buf[f"h{s}"], W[q + "fc2_w"], x2d, bias=W[q + "fc2_b"], epilogue=EPI_SCALE_RES,
-                         gamma=W[q + "gamma"], residual=x2d, x_planes=pl,
+                         gamma=W[q + "gamma"], residual=x2d, x_planes=pl, out16=None if xh is None else xh.view(-1, d),
                          prefetch=W.get(f"ds{s + 1}.w") if b == n - 1 else None)
         if cfg.main_backbone == "convnext":
             feat = x                                # (B,8,8,1024)

@@ -30,6 +30,8 @@ enum gp_dtype { GP_F32 = 0, GP_F16 = 1, GP_F64 = 2 /* gp_dcnv3_forward_any / gp_
  * worth of elements behind it, in y's fp32-sized storage) instead of fp32 -- the producer emits what gp_split_planes would make
  * of its result, and the consumer is gp_gemm(split_shift = GP_SPLIT_SHIFT) reading X = y.  y must not alias x. */
 #define GP_OUT_PLANES 0x100
+/* OR-ed into `dtype` = GP_F16 of gp_layernorm: the input rows are fp32 (the fp32 residual stream of the fp16 mode), the output fp16 */
+#define GP_IN_F32 0x200
 #define GP_SPLIT_SHIFT 11
 enum gp_act { GP_ACT_NONE = 0, GP_ACT_GELU = 1, GP_ACT_RELU = 2, GP_ACT_LRELU = 3 /* slope 0.1 */ };
 /* GEMM epilogues: v = acc + bias; then */
@@ -48,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 300 /* round 3: gp_gemm_desc grew (split-operand fields); round 2 (prefetch fields) was 200 */
+#define GP_ABI_VERSION 310 /* round 3: gp_gemm_desc grew (split-operand fields, fp32 residual stream fields); round 2 (prefetch fields) was 200 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -161,6 +163,12 @@ typedef struct gp_gemm_desc {
      * row stride ldc in fp16 elements) -- the X operand of the next split-operand gp_gemm -- instead of fp32; no split-K. */
     int out_planes;
     long c_plane_stride;
+    /* fp32 residual stream of the fp16 mode (dtype GP_F16, out_f32 != 0): residual_f32 != 0: `residual` is fp32 (row stride ldres
+     * in fp32 elements) -- variants 0 / 7 / 10; c16 != NULL: the output values are ALSO stored rounded to fp16 at c16 (row stride
+     * ldc16): the stream is accumulated in fp32 in C while the next consumer (depth-wise conv, LayerNorm) reads the fp16 copy. */
+    int residual_f32;
+    void* c16;
+    int ldc16;
 } gp_gemm_desc;
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 

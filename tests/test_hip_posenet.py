@@ -403,3 +403,29 @@ def test_grouped_launches_in_flight_bs128_stress():
             buf = net._plan(B, dev, i)["buf"]
             bad = [k for k, r in ref[i].items() if not torch.equal(buf[k], r)]
             assert not bad, (rep, i, bad)
+
+
+def test_fp16_with_fp32_residual_stream(oracle64):
+    """PoseNetConfig(res_fp32=True): the residual stream of ConvNeXt stage 2 accumulated in fp32 (fp32 residual / output of the
+    downsample conv and of every fc2, an fp16 copy for the depth-wise conv, fp32 rows into the next downsample LayerNorm).  Same
+    launches otherwise; the trunk feature must come out closer to the oracle's than the plain fp16 mode's, the poses at least as close
+    in the median; the model of tests/precision_model.py says 1.7 x on R."""
+    from givepose_amd import PoseNet, PoseNetConfig
+    data, ref = oracle64("dcnv3")
+    errs = {}
+    for name, cfg in (("fp16", PoseNetConfig()), ("res32", PoseNetConfig(res_fp32=True))):
+        net = PoseNet(cfg, dtype=torch.float16, seed=0, use_graph=True).cuda()
+        for _ in range(3):
+            out = net(data, "cuda")
+        dev_out = net.forward_device(data)
+        feat = dev_out["feat"].float().cpu().permute(0, 3, 1, 2)
+        per = (out["rot"].cpu() - ref["rot"]).abs().reshape(64, -1).max(1).values.sort().values
+        errs[name] = {"feat": float((feat - ref["feat"]).abs().max()), "feat_mean": float((feat - ref["feat"]).abs().mean()),
+                      "rot_median": float(per[32]), "rot_p90": float(per[57]), "rot_max": float(per[-1]),
+                      "size": float((out["size"].cpu() - ref["size"]).abs().max())}
+        if name == "res32":       # (labels need eager launches: a hipGraph replay carries no per-launch hooks)
+            labels = _launch_labels(PoseNet(cfg, dtype=torch.float16, seed=0).cuda(), _batch(4, 3))
+            assert sum(v for l, v in labels.items() if "N512 K2048 epi4" in l) == 27, labels
+    print("fp32 residual stream:", errs)
+    assert errs["res32"]["feat_mean"] < 0.8 * errs["fp16"]["feat_mean"]
+    assert errs["res32"]["rot_median"] < 1.1 * errs["fp16"]["rot_median"] and errs["res32"]["rot_p90"] < 2e-2
