@@ -415,7 +415,7 @@ class PoseNet(nn.Module):
                              gamma=W[q + "gamma"], residual=x2d)
                     continue
                 t = ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7, out_planes=self.split_gemm)
-                if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0:
+                if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0 and B >= cfg.fuse_mlp_min_batch:
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
                                      W[q + "gamma"], x2d, x2d)
                     continue

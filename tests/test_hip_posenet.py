@@ -188,20 +188,23 @@ def test_fp16_close_to_reference_golden(golden, net16, B):
     assert err["trans"] < 3e-2 * max(1.0, float(np.abs(z["out_trans"]).max()))
 
 
-@pytest.mark.parametrize("kw", [dict(defer_ln=True), dict(fuse_mlp=False)])
+@pytest.mark.parametrize("kw", [dict(defer_ln=True), dict(fuse_mlp=False), dict(fuse_mlp_min_batch=1)])
 def test_fp16_alternative_block_paths_close_to_reference_golden(golden, kw):
     """The switchable ConvNeXt block paths (LayerNorm folded into fc1's epilogue at C = 512; unfused fc1 / fc2 at
-    C = 128 / 256) meet the same fp16 tolerances as the default wiring."""
+    C = 128 / 256; the fused MLP kernel below its default batch threshold) meet the same fp16 tolerances as the default wiring."""
     z = golden("posenet_e2e_B4")
     net = _model(torch.float16, **kw)
     labels = _launch_labels(net, _batch(4, int(z["batch_seed"])))
     if "defer_ln" in kw:      # 27 stage-2 blocks through the raw depth-wise kernel + LayerNorm folded into fc1's epilogue
         assert sum(n for l, n in labels.items() if "gp_dwconv7_raw_stats" in l) == 27, labels
         assert sum(n for l, n in labels.items() if "N2048 K512 epi6" in l) == 27, labels
-    else:                     # no fused MLP launch; stages 0-1 run fc1 / fc2 as GEMMs
+    elif "fuse_mlp" in kw:    # no fused MLP launch; stages 0-1 run fc1 / fc2 as GEMMs
         assert not any("convnext_mlp" in l for l in labels), labels
         assert sum(n for l, n in labels.items() if " N512 K128 epi1" in l or " N1024 K256 epi1" in l) == 6, labels
-    assert any("convnext_mlp" in l for l in _launch_labels(_model(torch.float16), _batch(4, 3)))   # the default wiring does fuse
+    else:                     # the fused kernel at 4 crops (default: from PoseNetConfig.fuse_mlp_min_batch = 32 crops up)
+        assert sum(n for l, n in labels.items() if "convnext_mlp" in l) == 6, labels
+        assert not any("convnext_mlp" in l for l in _launch_labels(_model(torch.float16), _batch(4, 3)))
+        assert sum(n for l, n in _launch_labels(_model(torch.float16), _batch(32, 3)).items() if "convnext_mlp" in l) == 6
     out = net(_batch(4, int(z["batch_seed"])), "cuda")
     err = {k: float(np.abs(out[k].cpu().numpy() - z["out_" + k]).max()) for k in ("rot", "trans", "size", "nocs_coor", "ivfc_coor")}
     print("fp16", kw, err)
