@@ -6,8 +6,7 @@ from givepose_amd import PoseNet, PoseNetConfig, synth
 
 dev = torch.device("cuda:0")
 Bs = [int(a) for a in sys.argv[1:]] or [1, 4, 16]
-arms = [("fused MLP (stages 0-1)", dict(fuse_mlp_min_batch=1)), ("plain fc1 / fc2", dict(fuse_mlp=False)), ("defer_ln", dict(defer_ln=True, fuse_mlp_min_batch=1)),
-        ("default", {})]
+arms = [("default", {}), ("fused MLP (stages 0-1) at any batch", dict(fuse_mlp_min_batch=1)), ("plain fc1 / fc2", dict(fuse_mlp=False)), ("defer_ln", dict(defer_ln=True))]
 for B in Bs:
     one = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_batch(B, seed=1000).items()}
     res = {}
