@@ -76,7 +76,7 @@ def timed(fn, steps, fence, world, dev):
         fn()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -115,6 +115,8 @@ def spawn_ranks(n, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # this pool's host driver only supports dmabuf IPC: with the legacy mode RCCL's buffer exchange between the rank processes
+        # fails (`hipIpcGetMemHandle: invalid argument`).  The image exports the variable; kept for a hand-built environment.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
@@ -161,8 +163,9 @@ def main():
                          "weights); with --group G that is inflight * G batches in flight; 1 = strictly one launch after the other")
     ap.add_argument("--group", type=int, default=2,
                     help="batches per LAUNCH: G batches of --batch crops run as one launch sequence over G * batch crops (PoseNet "
-                         "dcn_couple: the DCNv3 offset coupling stays per batch, results bit for bit those of separate batches); a "
-                         "step is still ONE batch, so a launch counts as G steps")
+                         "dcn_couple: the DCNv3 offset coupling stays per batch; the poses are those of separate batches up to the "
+                         "GEMM schedules picked at G times the rows -- measured and bounded on the line: overlap_check."
+                         "grouped_vs_separate_batches); a step is still ONE batch, so a launch counts as G steps")
     ap.add_argument("--h2d", default=None, choices=["crops", "frames"],
                     help="put the host -> HBM transfer of every step's inputs INSIDE the timed step (pipelined on a copy stream); "
                          "the line then says so in config.inputs and is not the metric's `value` (inputs resident)")
@@ -188,7 +191,12 @@ def main():
     # GP_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (gloo backend, every rank on cuda:0);
     # the numbers mean nothing, the driver's real runs use RCCL with one rank per GPU
     rehearse = os.environ.get("GP_BENCH_REHEARSE") == "1"
-    rank, local, world = gd.init_from_env(backend="gloo" if rehearse else None)
+    # GP_BENCH_FORCE_COLLECTIVE=1 (with --gpus 1): the N > 1 control flow -- process group, pose all-gather inside the step, barrier
+    # fences -- on a ONE-rank RCCL communicator: what a one-GPU box can execute of RCCL (tests/test_rccl_single_rank.py)
+    force_coll = os.environ.get("GP_BENCH_FORCE_COLLECTIVE") == "1" and args.gpus == 1
+    rank, local, world = gd.init_from_env(backend="gloo" if rehearse else None, force=force_coll)
+    coll = world > 1 or force_coll
+    on_rccl = coll and not rehearse
     if rehearse:
         local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -209,7 +217,7 @@ def main():
     batches = [{k: np.concatenate([singles[i * G + j][k] for j in range(G)], 0) for k in host} for i in range(NF)]   # slot i: G batches per launch
 
     def make_runner(model, nslots, h2d, nb=BL):
-        r = ShardRunner(model, nb, dev, world, inflight=nslots, h2d=h2d)
+        r = ShardRunner(model, nb, dev, world, inflight=nslots, h2d=h2d, force_collective=force_coll)
         for i in range(nslots):
             if h2d == "frames":     # uint8 frames (4 detections per 640x480 frame) + uint8 masks + boxes travel; gp_crop_rois makes the crops
                 rng = np.random.default_rng(7 + i)
@@ -227,10 +235,15 @@ def main():
     n_launch, n_single = args.steps // G, args.steps % G
     run_single = make_runner(net, 1, args.h2d, nb=B) if (G > 1 and n_single) else None
 
+    def barrier():
+        if on_rccl:
+            dist.barrier(device_ids=[local])     # RCCL: name the device (without it the barrier's tensor goes to a guessed device)
+        elif coll:
+            dist.barrier()
+
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(max((args.warmup + G - 1) // G, 2 * NF)):  # per slot: first call eager, graph capture on the second
@@ -262,7 +275,11 @@ def main():
                    "batches_in_flight": NF * G,
                    "inputs": {None: "resident in HBM", "crops": "fp32 crops from pinned host memory every step (copy stream, pipelined)",
                               "frames": "uint8 frames + masks + boxes from pinned host memory every step, gp_crop_rois on the device"}[args.h2d],
-                   "collective": "all_gather (B,15) fp32 per rank, one comm stream" if world > 1 else "none"},
+                   "crops_per_launch": BL, "launch_sequences_in_flight": NF,
+                   "collective": ("all_gather (B,15) fp32 per rank over " + ("gloo (rehearsal)" if rehearse else "RCCL") + ", one comm stream"
+                                  + (" (ONE-rank communicator: GP_BENCH_FORCE_COLLECTIVE)" if force_coll else "")) if coll else "none"},
+        "value_launch_shape": (f"{NF} launch sequence(s) in flight x {G} batch(es) of {B} crops per launch = {BL}-crop launches; the bs-{B} "
+                               "launches strictly one after the other are `one_batch_in_flight`"),
         "path_roofline_frac_mfma": round(value / world * GFLOP_PER_CROP[args.workload] * 1e9 / (peak * 1e12), 4),
         "vs_reference": None,
     }
@@ -282,11 +299,12 @@ def main():
         grouped_vs_alone = None
         if G > 1:
             # A launch over G batches gives every batch the poses it gets alone -- bit for bit when both runs pick the same schedules
-            # (tests/test_hip_posenet.py::test_grouped_launch_equals_separate_batches); at other row counts the tile choice may differ
+            # (tests/test_grouped_launch.py::test_grouped_launch_equals_separate_batches; per batch against the oracle at 2 x 64:
+            # test_grouped_launch_bs128_matches_oracle_per_batch); at other row counts the tile choice may differ
             # (e.g. the 3x3 window kernel sums channel chunks outer / taps inner, the tap-by-tap kernel the other way round), which moves
             # the last fp16 bits.  So: measured and reported here, bounded like two numerically equivalent builds, not required bitwise.
             alone = PoseNet(cfg, seed=0, use_graph=False, inflight=1, **mode).to(dev)
-            dmax, bit = torch.zeros(3), True
+            dmax, bit = torch.zeros(4), True
             for j in range(G):
                 d1 = {k: torch.from_numpy(v).to(dev) for k, v in singles[j].items()}
                 o = alone.forward_device(d1, dev)
@@ -296,11 +314,16 @@ def main():
                 bit = bit and torch.equal(pa, mj)
                 dd = (pa - mj).abs()
                 per = dd[:, :9].max(1).values.sort().values
-                dmax = torch.maximum(dmax, torch.tensor([float(per[per.numel() // 2]), float(dd[:, 9:12].max()), float(dd[:, 12:].max())]))
+                dmax = torch.maximum(dmax, torch.tensor([float(per[per.numel() // 2]), float(dd[:, 9:12].max()), float(dd[:, 12:].max()), float(per[-1])]))
             del alone
-            grouped_vs_alone = {"bitwise": bool(bit), "rot_median_over_crops": float(dmax[0]), "trans": float(dmax[1]), "size": float(dmax[2])}
-            grouped_vs_alone["within_bound"] = bool(bit or float(dmax[0]) < (5e-3 if args.dtype == "f16" else 2e-5))
-        if world > 1:
+            grouped_vs_alone = {"bitwise": bool(bit), "rot_median_over_crops": float(dmax[0]), "rot_max_over_crops": float(dmax[3]),
+                                "trans": float(dmax[1]), "size": float(dmax[2]), "batches_compared": G}
+            # every batch of the launch (group 0 and group >= 1) against its own separate forward: median AND worst crop of |dR|, |dt|, |ds|
+            # bounded like two numerically equivalent builds of the mode (fp16: tests/test_hip_posenet.py's bounds against the oracle)
+            lim = {"f16": (5e-3, 8e-2, 3e-2, 3e-2)}.get(args.dtype, (2e-5, 1e-4, 2e-5, 2e-5))
+            grouped_vs_alone["bounds"] = dict(zip(("rot_median_over_crops", "rot_max_over_crops", "trans", "size"), lim))
+            grouped_vs_alone["within_bound"] = bool(bit or (float(dmax[0]) < lim[0] and float(dmax[3]) < lim[1] and float(dmax[1]) < lim[2] and float(dmax[2]) < lim[3]))
+        if coll:
             tt = torch.tensor([1 if same else 0], device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             same = bool(int(tt))
@@ -314,8 +337,8 @@ def main():
             note("FAILED: overlapped batches did not reproduce the serial replay bit for bit")
             if rank == 0:
                 print(json.dumps(line), flush=True)
-            if world > 1:
-                dist.barrier()
+            if coll:
+                barrier()
                 dist.destroy_process_group()
             sys.exit(3)
     if rank == 0:
@@ -365,7 +388,10 @@ def main():
             n, ms, fl, by = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             lib.gp_timing_report(c, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
             if n.value:
-                classes[name] = {"launches_per_step": n.value // reps, "ms_per_step": round(ms.value / reps, 4),
+                # a launch sequence covers G steps (batches): *_per_step is per batch of B crops (comparable with the line's
+                # ms_per_step), *_per_launch_sequence what one pass of the eager sequence over BL crops took
+                classes[name] = {"launches_per_step": round(n.value / reps / G, 2), "ms_per_step": round(ms.value / reps / G, 4),
+                                 "launches_per_launch_sequence": n.value // reps, "ms_per_launch_sequence": round(ms.value / reps, 4),
                                  "avg_launch_us": round(ms.value / n.value * 1e3, 2),
                                  "tflops": round(fl.value / ms.value / 1e9, 2), "gbs": round(by.value / ms.value / 1e6, 1),
                                  "alg_bytes_per_launch": round(by.value / n.value), "alg_flop_per_launch": round(fl.value / n.value)}
@@ -377,8 +403,9 @@ def main():
                 break
             mfma = c.value == _lib.KC_GEMM
             ach = fl.value / ms.value / 1e9 if mfma else by.value / ms.value / 1e6
-            top.append({"kernel": lab.value.decode(), "launches_per_step": n.value // reps, "ms_per_step": round(ms.value / reps, 4),
-                        "avg_launch_us": round(ms.value / n.value * 1e3, 2), "bound": "mfma" if mfma else "hbm",
+            top.append({"kernel": lab.value.decode(), "launches_per_step": round(n.value / reps / G, 2), "ms_per_step": round(ms.value / reps / G, 4),
+                        "launches_per_launch_sequence": n.value // reps, "ms_per_launch_sequence": round(ms.value / reps, 4),
+                        "avg_launch_us": round(ms.value / n.value * 1e3, 2), "crops_per_launch": BL, "bound": "mfma" if mfma else "hbm",
                         "achieved": round(ach, 1), "unit": "TFLOP/s" if mfma else "GB/s",
                         "frac": round(ach / (peak if mfma else PEAK_HBM_GBS), 4)})
         g = classes["gemm"]
@@ -386,7 +413,8 @@ def main():
                                       + ("step" if G == 1 else f"launch sequence over {G} batches ({BL} crops)"),
                             "bound": "mfma", "achieved": g["tflops"], "peak": peak, "unit": "TFLOP/s",
                             "frac": round(g["tflops"] / peak, 4), "traffic": None,
-                            "launches_per_step": g["launches_per_step"], "avg_launch_us": g["avg_launch_us"],
+                            "launches_per_step": g["launches_per_step"], "launches_per_launch_sequence": g["launches_per_launch_sequence"],
+                            "avg_launch_us": g["avg_launch_us"],
                             "alg_flop_per_launch": g["alg_flop_per_launch"], "alg_bytes_per_launch": g["alg_bytes_per_launch"],
                             "kernels": top[:3], "crops_per_launch": BL}
         if "dcnv3" in classes:
@@ -413,7 +441,8 @@ def main():
         if args.kernels_out:
             with open(args.kernels_out, "w") as f:
                 json.dump(top, f, indent=1)
-        line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_step"] for c in classes.values()), 3)
+        line["eager_ms_per_step_sum_of_kernels"] = round(sum(c["ms_per_launch_sequence"] for c in classes.values()) / G, 3)
+        line["eager_ms_per_launch_sequence_sum_of_kernels"] = round(sum(c["ms_per_launch_sequence"] for c in classes.values()), 3)
 
     if rank == 0:
         note("roofline leg done")
@@ -552,8 +581,8 @@ def main():
         if commit:
             line["commit"] = commit
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if coll:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -21,6 +21,17 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-val
 # GP_PACKED_FP32=1 re-enables them for A/B runs.  (The x86 host pass ignores the unknown target feature with a warning.)
 if os.environ.get("GP_PACKED_FP32") != "1":
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Wno-unknown-warning-option"]
+# Investigation builds (never the product library): GP_EXTRA_HIPCC_FLAGS="-DGP_WREG_STAMPS ..." adds compiler flags and
+# GP_BUILD_TAG=<tag> writes libgivepose_hip_<tag>.so from its own object directory, so that the product .so next to it stays
+# untouched; load it with GP_LIB_PATH (givepose_amd/_lib.py).  scripts/wreg_stamps.py, scripts/profile_r04.sh.
+EXTRA = os.environ.get("GP_EXTRA_HIPCC_FLAGS", "").split()
+TAG = os.environ.get("GP_BUILD_TAG", "")
+if EXTRA and not TAG:
+    raise RuntimeError("GP_EXTRA_HIPCC_FLAGS needs GP_BUILD_TAG: an investigation build must not overwrite the product library")
+if TAG:
+    OBJ = os.path.join(HERE, "csrc", "build", "tag_" + TAG)
+    LIB = os.path.join(HERE, f"libgivepose_hip_{TAG}.so")
+    FLAGS += EXTRA
 
 
 def _newer(a, b):

@@ -53,8 +53,7 @@ __global__ __launch_bounds__(256) void dcnv3_any_fwd_kernel(const AnyKP p) {
     const T* im = reinterpret_cast<const T*>(p.in) + (long)b * p.H * p.W * cs + (long)g * p.D;
     T* out = reinterpret_cast<T*>(p.out) + wid * p.D;
     A w1 = 0, w2 = 0, w3 = 0, w4 = 0, mw = 0;     // lane t: tap (q0 + t)
-    long o11 = 0;
-    int ex = 0, ey = 0;
+    long o11 = 0, ex = 0, ey = 0;       // element offsets (long: W * G * D overflows an int on large tensors)
     auto own_tap = [&](int q0) {
         const int q = q0 + lane;
         w1 = w2 = w3 = w4 = mw = 0;
@@ -75,8 +74,8 @@ __global__ __launch_bounds__(256) void dcnv3_any_fwd_kernel(const AnyKP p) {
                 w4 = (bo && r) ? lh * lw : (A)0;
                 const int cy0 = max(y0, 0), cy1 = min(y1, p.H - 1), cx0 = max(x0, 0), cx1 = min(x1, p.W - 1);
                 o11 = ((long)cy0 * p.W + cx0) * cs;
-                ex = (int)((cx1 - cx0) * cs);
-                ey = (int)((long)(cy1 - cy0) * p.W * cs);
+                ex = (long)(cx1 - cx0) * cs;
+                ey = (long)(cy1 - cy0) * p.W * cs;
                 mw = (A)msk[q];
             }
         }
@@ -91,10 +90,13 @@ __global__ __launch_bounds__(256) void dcnv3_any_fwd_kernel(const AnyKP p) {
                 const A a1 = __shfl(w1, s, 64), a2 = __shfl(w2, s, 64), a3 = __shfl(w3, s, 64), a4 = __shfl(w4, s, 64);
                 const A wg = __shfl(mw, s, 64);
                 const long o = __shfl(o11, s, 64);
-                const int dx = __shfl(ex, s, 64), dy = __shfl(ey, s, 64);
+                const long dx = __shfl(ex, s, 64), dy = __shfl(ey, s, 64);
                 if (c < p.D) {
                     const T* q = im + o + c;
-                    const A v1 = (A)q[0], v2 = (A)q[dx], v3 = (A)q[dy], v4 = (A)q[dx + dy];
+                    // a corner outside the image is fetched from a clamped address: SELECT it away (the reference skips the load,
+                    // cuh:50-68) -- a multiplication by the zero weight would let a NaN / Inf at the clamped pixel through
+                    const A v1 = a1 != (A)0 ? (A)q[0] : (A)0, v2 = a2 != (A)0 ? (A)q[dx] : (A)0;
+                    const A v3 = a3 != (A)0 ? (A)q[dy] : (A)0, v4 = a4 != (A)0 ? (A)q[dx + dy] : (A)0;
                     col += (a1 * v1 + a2 * v2 + a3 * v3 + a4 * v4) * wg;
                 }
             }

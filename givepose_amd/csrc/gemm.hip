@@ -1526,6 +1526,9 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
+    // c16 is written by the generic epilogue of gemm_big_kernel only (out_f32 keeps every tile off the lean one); the window conv
+    // and the weights-in-registers kernel would return without it
+    GP_REQUIRE(!d->c16 || (variant != 13 && variant != 16 && !split), "gp_gemm: c16 runs on the tile kernels (variants 2-5, 7-12), not on %d%s", variant, split ? " split" : "");
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 16) {
@@ -1540,6 +1543,13 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
 #ifdef GP_WREG_STAMPS   // investigation build (GP_EXTRA_HIPCC_FLAGS=-DGP_WREG_STAMPS): variant 1616 = the same kernel with s_memtime
                         // stamps of workgroup 0 into the workspace (scripts/wreg_stamps.py); spills 7 registers -> never in the product
                 if (p.dbg == 16 && p.ws) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_GELU, 16>), dim3(grid), dim3(512), 0, s, p); break; }
+                // timing ablations (wrong results): 1 no MFMA, 2 no stores, 4 no in-loop DMA, 8 no GELU in the MFMA shadow (and none at all), 10 = 8 + 2
+                if (p.dbg == 1) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_GELU, 1>), dim3(grid), dim3(512), 0, s, p); break; }
+                if (p.dbg == 2) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_GELU, 2>), dim3(grid), dim3(512), 0, s, p); break; }
+                if (p.dbg == 4) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_GELU, 4>), dim3(grid), dim3(512), 0, s, p); break; }
+                if (p.dbg == 8) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_NONE, 8>), dim3(grid), dim3(512), 0, s, p); break; }
+                if (p.dbg == 10) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_NONE, 10>), dim3(grid), dim3(512), 0, s, p); break; }
+                if (p.dbg == 14) { hipLaunchKernelGGL((gemm_wreg_kernel<GP_EPI_NONE, 14>), dim3(grid), dim3(512), 0, s, p); break; }
 #endif
                 hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_GELU>, dim3(grid), dim3(512), 0, s, p);
                 break;

@@ -14,12 +14,14 @@ import torch.distributed as dist
 POSE_WIDTH = 15  # 9 (R row-major) + 3 (t) + 3 (s)
 
 
-def init_from_env(backend=None):
-    """(rank, local_rank, world) from the torchrun env; initialises the default group when world > 1."""
+def init_from_env(backend=None, force=False):
+    """(rank, local_rank, world) from the torchrun env; initialises the default group when world > 1 -- or, with `force`, also
+    for world == 1: a ONE-rank RCCL communicator, so that a one-GPU box can exercise communicator creation, the collective and
+    the barrier of the N > 1 path (tests/test_rccl_single_rank.py, GP_BENCH_FORCE_COLLECTIVE=1 in bench.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -67,10 +69,11 @@ def unpack_poses(p):
     return p[:, :9].reshape(-1, 3, 3), p[:, 9:12], p[:, 12:15]
 
 
-def all_gather_poses(local, world: int, out=None, group=None):
+def all_gather_poses(local, world: int, out=None, group=None, force=False):
     """local (per, 15) -> (world*per, 15), rank-major = global crop order.  Equal shard sizes use the fused
-    all_gather_into_tensor; ragged shards fall back to the list form."""
-    if world == 1:
+    all_gather_into_tensor; ragged shards fall back to the list form.  force: run the collective for world == 1 too (a
+    one-rank communicator: init_from_env(force=True))."""
+    if world == 1 and not force:
         return local
     sizes = [None] * world
     if out is not None or _equal_shards(local, world, group):

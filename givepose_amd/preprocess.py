@@ -85,8 +85,12 @@ def crop_params(bboxes, im_H, im_W, img_size=256, out_res=64, pad_scale=1.5):
     vectorised over the detections (a 64-detection batch costs ~0.2 ms of host time instead of ~6)."""
     bboxes = np.asarray(bboxes, dtype=np.float64).reshape(-1, 4)
     y1, x1, y2, x2 = bboxes[:, 0], bboxes[:, 1], bboxes[:, 2], bboxes[:, 3]
+    ext = np.maximum(y2 - y1, x2 - x1)
+    if not np.all(np.isfinite(bboxes)) or np.any(ext <= 0):      # a zero-extent box has no crop (scale 0: singular map, inf ratio);
+        bad = np.nonzero(~(np.isfinite(bboxes).all(1) & (ext > 0)))[0]   # name it instead of failing the whole batch in the solve
+        raise ValueError(f"crop_params: degenerate detection box(es) at index {bad.tolist()}: (y1,x1,y2,x2) = {bboxes[bad].tolist()}")
     cx, cy = 0.5 * (x1 + x2), 0.5 * (y1 + y2)
-    scale = np.minimum(np.maximum(y2 - y1, x2 - x1) * pad_scale, max(im_H, im_W)) * 1.0
+    scale = np.minimum(ext * pad_scale, max(im_H, im_W)) * 1.0
     inv_img = _invert_batch(_affine_dst_from_src_batch(cx, cy, scale, float(img_size)))
     inv_out = _invert_batch(_affine_dst_from_src_batch(cx, cy, scale, float(out_res)))
     wh = np.stack([np.minimum(im_W, x2) - np.maximum(0, x1), np.minimum(im_H, y2) - np.maximum(0, y1)], 1).astype(np.float32)

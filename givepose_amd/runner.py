@@ -18,8 +18,11 @@ class ShardRunner:
     slot's stream turns it into the model's static inputs (one device copy / the crop kernel) right in front of its
     hipGraph, so the PCIe traffic of step n + 1 overlaps the kernels of step n."""
 
-    def __init__(self, net, batch, device, world=1, inflight=None, h2d=None, frame_hw=(480, 640)):
+    def __init__(self, net, batch, device, world=1, inflight=None, h2d=None, frame_hw=(480, 640), force_collective=False):
+        """force_collective: run the pack + all-gather of the N > 1 step for world == 1 as well (a one-rank RCCL communicator
+        made by dist.init_from_env(force=True)): the only way a one-GPU box can execute the collective path on RCCL itself."""
         self.net, self.B, self.dev, self.world = net, batch, torch.device(device), world
+        self.collective = world > 1 or bool(force_collective)
         self.NF = max(1, net.inflight if inflight is None else inflight)
         if self.NF > 1 and not net.use_graph:
             raise ValueError("batches in flight need the hipGraph path (per-slot streams)")
@@ -28,8 +31,8 @@ class ShardRunner:
         self.h2d = h2d
         self.statics = [net.static_inputs(batch, self.dev, slot=i) for i in range(self.NF)]
         self.poses = [torch.empty(batch, gd.POSE_WIDTH, device=self.dev) for _ in range(self.NF)]
-        self.gathered = [torch.empty(world * batch, gd.POSE_WIDTH, device=self.dev) for _ in range(self.NF)] if world > 1 else None
-        self.comm = torch.cuda.Stream(device=self.dev) if world > 1 else None
+        self.gathered = [torch.empty(world * batch, gd.POSE_WIDTH, device=self.dev) for _ in range(self.NF)] if self.collective else None
+        self.comm = torch.cuda.Stream(device=self.dev) if self.collective else None
         self.packed = [None] * self.NF      # event: the previous poses of slot i have been packed (its outputs may be overwritten)
         self.count = 0
         self.last = None
@@ -51,7 +54,8 @@ class ShardRunner:
             t = torch.as_tensor(v)
             self.statics[slot][k].copy_(t.reshape(self.statics[slot][k].shape))
         if self.h2d == "crops":
-            self.pinned[slot] = {k: torch.as_tensor(v).reshape(self.statics[slot][k].shape).to(torch.float32).contiguous().pin_memory()
+            # pinned in the static input's own dtype: the per-step transfer is a plain copy into a buffer of that dtype
+            self.pinned[slot] = {k: torch.as_tensor(v).reshape(self.statics[slot][k].shape).to(self.statics[slot][k].dtype).contiguous().pin_memory()
                                  for k, v in host_batch.items()}
             self.staging[slot] = {k: torch.empty_like(self.statics[slot][k]) for k in host_batch}
             self.host_bytes = sum(v.numel() * v.element_size() for v in self.pinned[slot].values())
@@ -97,6 +101,9 @@ class ShardRunner:
         """One pass of the whole path over one batch; consecutive steps use consecutive slots and overlap on the device
         (nothing is skipped: every step replays the full launch sequence on its own buffers)."""
         i = self.count % self.NF
+        if self.h2d and (self.pinned[i] is None or self.staging[i] is None):
+            raise RuntimeError(f"ShardRunner(h2d={self.h2d!r}): slot {i} has no host inputs -- call load() / load_frames() for every one of "
+                               f"the {self.NF} slots before step()")
         self.count += 1
         cur = torch.cuda.current_stream(self.dev)
         if self.packed[i] is not None:
@@ -104,7 +111,7 @@ class ShardRunner:
         if self.h2d:
             self._bring_inputs(i, cur)
         out = self.net.forward_device(self.statics[i], self.dev, slot=i, wait=self.NF == 1)
-        if self.world > 1:
+        if self.collective:
             done = torch.cuda.Event()
             done.record(self.net.stream(i) if self.net.use_graph else cur)
             self.comm.wait_event(done)
@@ -113,14 +120,14 @@ class ShardRunner:
                 ev = torch.cuda.Event()
                 ev.record(self.comm)
                 self.packed[i] = ev
-                gd.all_gather_poses(self.poses[i], self.world, out=self.gathered[i])
+                gd.all_gather_poses(self.poses[i], self.world, out=self.gathered[i], force=True)
         self.last = (i, out)
         return out
 
     def result(self, slot=None):
         """(world*B, 15) gathered poses of `slot` (default: the last step's), valid after a device synchronise."""
         i = self.last[0] if slot is None else slot
-        if self.world > 1:
+        if self.collective:
             return self.gathered[i]
         o = self.net._plan(self.B, self.dev, i)["buf"]
         return gd.pack_poses(o["rot_ego"].view(self.B, 3, 3), o["trans"], o["size"])
@@ -131,25 +138,32 @@ def rank_selfcheck(rank, world, port, queue, batch=8, steps=6, inflight=2, backe
     fork server that never touched the GPU): runs `steps` steps of the real step path (ShardRunner: slots in flight, one
     comm stream, all-gather of the poses) and reports, per slot, the gathered (world*B, 15) poses of its last use next
     to this rank's own poses computed strictly serially (eager, slot 0) on a separate PoseNet.  backend "gloo" lets every rank share
-    one GPU (RCCL refuses two ranks per device); the driver's real runs use "nccl" = RCCL with one rank per GPU."""
+    one GPU (RCCL refuses two ranks per device); the driver's real runs use "nccl" = RCCL with one rank per GPU.
+    world == 1 with backend "nccl": the same step path on a ONE-rank RCCL communicator (communicator creation,
+    all_gather_into_tensor on the comm stream, barrier) -- what a one-GPU box can execute of RCCL (tests/test_rccl_single_rank.py)."""
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(device_index if backend == "nccl" else rank))
+    # this pool's host driver only supports dmabuf IPC: without it RCCL's buffer exchange fails with `hipIpcGetMemHandle: invalid
+    # argument` (the image exports the variable; kept for environments built by hand)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         import torch.distributed as dist
         from . import PoseNet, PoseNetConfig, synth
-        gd.init_from_env(backend=backend)
+        gd.init_from_env(backend=backend, force=world == 1)
         torch.cuda.set_device(device_index)
         dev = torch.device("cuda", device_index)
+        barrier = (lambda: dist.barrier(device_ids=[device_index])) if backend == "nccl" else dist.barrier
         cfg = PoseNetConfig()
         net = PoseNet(cfg, dtype=torch.float16, seed=0, use_graph=True, inflight=inflight).to(dev)
-        run = ShardRunner(net, batch, dev, world)
+        run = ShardRunner(net, batch, dev, world, force_collective=world == 1)
         batches = [synth.synth_batch(batch, seed=500 + 10 * rank + i) for i in range(run.NF)]
         for i, b in enumerate(batches):
             run.load(i, b)
         for _ in range(steps):
             run.step()
         torch.cuda.synchronize(dev)
-        dist.barrier()
+        barrier()
         gathered = [run.result(i).cpu().numpy() for i in range(run.NF)]
         serial = PoseNet(cfg, dtype=torch.float16, seed=0, use_graph=False, inflight=inflight).to(dev)   # same tile choices, run strictly serially
         own = []
@@ -157,7 +171,7 @@ def rank_selfcheck(rank, world, port, queue, batch=8, steps=6, inflight=2, backe
             o = serial.forward_device({k: torch.from_numpy(v) for k, v in b.items()}, dev)
             own.append(gd.pack_poses(o["rot"], o["trans"], o["size"]).cpu().numpy())
         queue.put((rank, "ok", gathered, own))
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     except Exception as e:   # the parent must never wait for a dead rank
         import traceback

@@ -156,7 +156,7 @@ typedef struct gp_gemm_desc {
      *   ELEMENTS behind it (gp_split_planes makes them; weights are split once by the host); the kernel accumulates
      *   x_hi w_lo' + x_lo' w_hi, scales by 2^-S (exact) and adds x_hi w_hi, all in fp32: |error| ~ 2^-22 |x||w| per product,
      *   i.e. what an fp32 GEMM's own accumulation rounding amounts to.  Requires dtype GP_F16, out_f32 != 0 (C fp32);
-     *   residual (if any) is fp32; ldx / Cin / K address one plane; variant 0 / 4 / 7 / 8 / 10. */
+     *   residual (if any) is fp32; ldx / Cin / K address one plane; variant 0 / 4 / 7 / 8 / 10 / 13 (the 3x3 window conv). */
     int split_shift;
     long x_plane_stride, w_plane_stride;
     /* split-operand mode only, out_planes != 0: C is written as fp16 planes (hi at C, lo' c_plane_stride elements behind it,

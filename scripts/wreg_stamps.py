@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from givepose_amd import ops
 dev = "cuda"
-M, N, K = 16384, 2048, 512
+M, N, K = int(os.environ.get("M", 16384)), 2048, 512
 x = torch.randn(M, K).half().to(dev); w = (torch.randn(N, K) * K ** -0.5).half().to(dev); b = torch.randn(N).to(dev)
 out = torch.empty(M, N, dtype=torch.float16, device=dev)
 st = torch.zeros(8 * 32 * 6, dtype=torch.int64, device=dev)
