@@ -298,9 +298,9 @@ def main():
             same = same and torch.equal(gd.pack_poses(o["rot"], o["trans"], o["size"]), mine[i])
         grouped_vs_alone = None
         if G > 1:
-            # A launch over G batches gives every batch the poses it gets alone -- bit for bit when both runs pick the same schedules
+            # A launch over G batches gives every batch the poses it gets alone up to the summation order
             # (tests/test_grouped_launch.py::test_grouped_launch_equals_separate_batches; per batch against the oracle at 2 x 64:
-            # test_grouped_launch_bs128_matches_oracle_per_batch); at other row counts the tile choice may differ
+            # test_grouped_launch_bs128_matches_oracle_per_batch): at other row counts the tile choice may differ
             # (e.g. the 3x3 window kernel sums channel chunks outer / taps inner, the tap-by-tap kernel the other way round), which moves
             # the last fp16 bits.  So: measured and reported here, bounded like two numerically equivalent builds, not required bitwise.
             alone = PoseNet(cfg, seed=0, use_graph=False, inflight=1, **mode).to(dev)

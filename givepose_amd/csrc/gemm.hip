@@ -1332,6 +1332,196 @@ __global__ __launch_bounds__(512) void gemm_wreg_kernel(const GemmKP p) {
     stores(T - 1);
 }
 
+// =====================================================================================================
+// Weights-in-registers GEMM, second form (variant 17, round 4; the default for stage-2 fc1): the arithmetic of gemm_wreg_kernel
+// (bitwise the same results, scripts/wreg2_ab.py and tests/test_hip_ops.py) with what its ablations and s_memtime stamps
+// (profiles/r04_wreg_ablation.txt, r04_wreg_stamps.txt) pointed at:
+//  * the stores were 8 bytes per lane (32-byte runs, four per tile and wave; the kernel without them: 75 of 85 us).  The 32
+//    output channels of a wave are re-ordered -- row i of A fragment nt holds channel 8 (i / 4) + 4 nt + i % 4, a free choice of
+//    which W rows a fragment is loaded from -- so that a lane's two n-tiles are 8 CONSECUTIVE channels: one 16-byte store per
+//    lane and m-tile (64-byte runs), half the store instructions;
+//  * one GELU slice of TWO chains behind every MFMA (24 of a half tile's 32 MFMAs) instead of four chains in lock step: 12
+//    scratch registers instead of 24, no change in the instruction count;
+//  * DMA lead 2 tiles (the pieces of tile t+2 ride in tile t): one whole tile for them to land, the wait in front of the barrier
+//    never waits.
+// Measured against variant 16 (interleaved medians, two boxes): 42.4 / 76.2 against 44.8 / 81.0 us at M = 16384 / 32768.  What
+// was also built on this kernel and measured to be worth nothing or less (profiles/r04_wreg2_ab.txt, arms removed again): waves 4-7
+// half a tile behind waves 0-3 with their barrier in the middle of the tile (+2-3 % TIME: MI355X_MICROARCH.md's stagger does
+// not carry over to a tile whose every K step mixes MFMA and VALU), s_setprio 1 for waves 4-7 (nothing), B fragments 3 / 4
+// instead of 2 K steps ahead (nothing: the LDS latency is not what it waits for), the four DMA pieces back to back behind the
+// barrier (nothing).  The ablations say why: the MFMAs + fragment reads + barrier alone take 55 of the 85 us (1 250 TFLOP/s,
+// the rate the best tile kernels of this library reach on random data), and GELU (10 us), stores (9) and DMA (9) ADD to that
+// instead of hiding under it: on a SIMD with two waves of the same program, vector-issue time is the sum of both waves' MFMA,
+// VALU, LDS and DMA instructions.
+// LDS ring and hazards (NBUF = 4 tiles of 32 rows, tile t in buffer t & 3; b_t = the barrier that ends tile t):
+//   RAW: every wave waits for ITS four DMA pieces of tile t+1 (counted vmcnt) in front of b_t.  WAR: buffer (t+2) & 3 held tile
+//   t-2, whose last reads lie in front of b_t-2: the pieces of tile t+2 are issued during tile t.  vmcnt counts in issue order, DMA
+//   pieces and stores alike; every store is ONE inline-asm instruction; allowed() counts what a wave issued behind the pieces it
+//   waits for.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_wreg2_kernel(const GemmKP p) {
+    constexpr int K = 512, KS = K / 32, TM = 32, NBUF = 4, BUFB = TM * K * 2, NT = 2, MT = 2;
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUFB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsl = p.N >> 8;
+    const int bid = blockIdx.x;
+    const int item = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // XCD-contiguous chunks of the (m group, n slice) list (host: gridDim.x % 8 == 0)
+    const int mg = item / nsl, ns = item - mg * nsl;
+    const long m0 = (long)mg * p.tiles_m * TM;
+    const int T = min(p.tiles_m, (int)((p.M - m0) / TM));
+    if (T <= 0) return;
+    const int nb = ns * 256 + wave * 32;
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    const char* xsrc = reinterpret_cast<const char*>(p.X) + ((m0 + wave * 4) * (long)p.ldx) * 2;
+    const long rowb = (long)p.ldx * 2;
+    unsigned xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xoff[i] = (unsigned)(i * rowb) + ((lane ^ ((wave * 4 + i) & 15)) << 4);
+    auto piece = [&](int t, int i) {          // piece i (one row of 1 KB, chunk-swizzled on the source side) of this wave's four rows of tile t
+        glds16_s(xsrc + (long)t * TM * rowb, xoff[i], lds0 + (t & (NBUF - 1)) * BUFB + (wave * 4 + i) * 1024);
+    };
+    // B fragment (mt, ks) of a tile: row mt*16 + fr, chunk (ks*4 + fq) ^ fr = ((ks & 3)*4 ^ (fq ^ fr)) + (ks >> 2) * 16
+    unsigned boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = fr * 1024 + (((j * 4) ^ (fq ^ fr)) << 4);
+
+    uint4 wf[NT][KS];
+    f32x4 b4[NT], acc[NT][MT];
+    f32x2 v[NT * MT * 2];   // pre-activation values of the previous tile: v[mt * 4 + nt * 2 + {0, 1}]
+    // lane (fr, fq) owns row m0 + t TM + mt 16 + fr, channels nb + 8 fq .. + 8 (n-tile nt: + 4 nt .. + 4)
+    half_t* Cw = reinterpret_cast<half_t*>(p.C) + (m0 + fr) * (long)p.ldc + nb + fq * 8;
+    f32x2 gx[2], gt[2], gp[2];
+    float c1v = GELU_H[1];
+    asm volatile("" : "+v"(c1v));
+
+    // in front of b_t a wave has issued, behind its pieces of tile t+1 (K steps 2..14 of tile t-1): stores(t-2), the pieces of tile
+    // t+2 (if it exists) and stores(t-1)
+    auto allowed = [&](int t) { return (t >= 2 ? MT : 0) + (t + 2 < T ? 4 : 0) + (t >= 1 ? MT : 0); };
+    auto sync = [&](int t) {       // RAW wait for the own pieces of tile t+1, then the tile's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= 2 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // steady state: 2 + 4 + 2
+        else wait_vmcnt_n(allowed(t));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stores = [&](int t) {   // MT stores of 16 bytes per lane, one instruction each
+        half_t* c = Cw + (long)t * TM * p.ldc;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x2 a = v[mt * 4], b = v[mt * 4 + 1], cc = v[mt * 4 + 2], d = v[mt * 4 + 3];
+            const half8 o = {(half_t)a[0], (half_t)a[1], (half_t)b[0], (half_t)b[1], (half_t)cc[0], (half_t)cc[1], (half_t)d[0], (half_t)d[1]};
+            const pf_u32x4 ov = __builtin_bit_cast(pf_u32x4, o);
+            const half_t* dst = c + (long)mt * 16 * p.ldc;
+            // (s_nop 1 inside the string: a store of more than 8 bytes reads its data registers for two more states, and hipcc pads
+            // nothing around an asm statement -- its next v_cvt_pk into the same registers otherwise clobbers the fourth dword)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+        }
+    };
+    auto take = [&]() {   // accumulators -> v (v[mt * 4 + nt * 2 + h] = registers 2 h, 2 h + 1 of acc[nt][mt]), accumulators back to the bias
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 a = acc[nt][mt];
+                acc[nt][mt] = b4[nt];
+                v[mt * 4 + nt * 2] = f32x2{a[0], a[1]};
+                v[mt * 4 + nt * 2 + 1] = f32x2{a[2], a[3]};
+            }
+    };
+    auto activate = [&]() {
+        if constexpr (EPI == GP_EPI_GELU) {
+            gelu_poly2_xn<4>(v);
+            gelu_poly2_xn<4>(v + 4);
+        } else if constexpr (EPI == GP_EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{fmaxf(v[i][0], 0.0f), fmaxf(v[i][1], 0.0f)};
+        } else if constexpr (EPI == GP_EPI_LRELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{v[i][0] > 0.0f ? v[i][0] : 0.1f * v[i][0], v[i][1] > 0.0f ? v[i][1] : 0.1f * v[i][1]};
+        }
+    };
+    // one tile: 64 MFMAs with the activation of the previous tile's values in their shadow (K steps 0-7: v[0..3] = m-tile 0,
+    // K steps 8-15: v[4..7] = m-tile 1; MFMA i of a half tile carries slice i % 12 of chain pair i / 12), B fragments read two
+    // K steps ahead, one DMA piece of tile t+2 at K steps 2 / 6 / 10 / 14.  sched_barriers pin the order (hipcc otherwise clusters
+    // the VALU work and waits lgkmcnt(0) in front of every MFMA pair).
+    auto tile = [&](int t, auto shadow) {
+        constexpr bool SH = decltype(shadow)::value && EPI == GP_EPI_GELU;
+        const char* xb = smem + (t & (NBUF - 1)) * BUFB;
+        uint4 bf[3][MT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                bf[ks][mt] = *reinterpret_cast<const uint4*>(xb + boff[ks & 3] + mt * 16 * 1024 + (ks >> 2) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (ks + 2 < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    bf[(ks + 2) % 3][mt] = *reinterpret_cast<const uint4*>(xb + boff[(ks + 2) & 3] + mt * 16 * 1024 + ((ks + 2) >> 2) * 256);
+            }
+            if constexpr (ks % 4 == 2) {
+                if (t + 2 < T) piece(t + 2, ks / 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NT * MT>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, nt = j / MT, mt = j % MT;
+                mma<half_t>(acc[nt][mt], wf[nt][ks], bf[ks % 3][mt]);
+                if constexpr (SH) {
+                    constexpr int half = ks / 8, i = (ks % 8) * 4 + j, cp = i / GELU_SLICES, slot = i % GELU_SLICES;
+                    if constexpr (cp < 2) {
+                        gelu_poly2_slice<slot>(v[half * 4 + cp * 2], gx[0], gt[0], gp[0], c1v);
+                        gelu_poly2_slice<slot>(v[half * 4 + cp * 2 + 1], gx[1], gt[1], gp[1], c1v);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+
+    // ---- prologue: tiles 0 and 1, the resident W fragments, the bias
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < T)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece(t, i);
+    const PfSink pfs = prefetch_issue(p, bid, gridDim.x, wave, 8, lane);
+    // lane (fr, fq) of fragment (nt, ks) holds W[nb + 8 (fr / 4) + 4 nt + fr % 4][ks * 32 + fq * 8 .. + 8]
+    const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + (fr >> 2) * 8 + (fr & 3)) * K + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[nt][ks] = *reinterpret_cast<const uint4*>(Wp + (long)nt * 4 * K + ks * 32);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        b4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + fq * 8 + nt * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc does not wait for the W loads inside the loop
+    prefetch_retire(pfs);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b4[nt];
+    __builtin_amdgcn_s_barrier();         // tiles 0 and 1 are published
+
+    tile(0, std::false_type{});
+    take();
+    sync(0);
+    for (int t = 1; t < T; ++t) {
+        tile(t, std::true_type{});
+        if constexpr (EPI != GP_EPI_GELU) activate();
+        __builtin_amdgcn_sched_barrier(0);
+        stores(t - 1);
+        take();
+        sync(t);
+    }
+    activate();
+    stores(T - 1);
+}
+
 template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, int RB = 128, bool PP = false, bool SPL = false, bool R32 = false> void launch_big(GemmKP& p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     p.nkt = p.K / (RB / (int)sizeof(T));
@@ -1509,7 +1699,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // against; measured, scripts/split_variants.py: it wins from ~140 tiles of 256 x 256 up, below that the 128 x 128
             // two-workgroups-per-CU tile does; the 256 x 128 tile never)
             if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
-            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = 16;
+            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = (d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0) ? 17 : 16;
             else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= co_min_tiles()) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
@@ -1523,12 +1713,12 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (!d->out_f32 || split) && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 && !d->out_planes &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
-    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
+    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16 || variant == 17) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
     // c16 is written by the generic epilogue of gemm_big_kernel only (out_f32 keeps every tile off the lean one); the window conv
     // and the weights-in-registers kernel would return without it
-    GP_REQUIRE(!d->c16 || (variant != 13 && variant != 16 && !split), "gp_gemm: c16 runs on the tile kernels (variants 2-5, 7-12), not on %d%s", variant, split ? " split" : "");
+    GP_REQUIRE(!d->c16 || (variant != 13 && variant != 16 && variant != 17 && !split), "gp_gemm: c16 runs on the tile kernels (variants 2-5, 7-12), not on %d%s", variant, split ? " split" : "");
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 16) {
@@ -1556,6 +1746,22 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             case GP_EPI_RELU: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_RELU>, dim3(grid), dim3(512), 0, s, p); break;
             case GP_EPI_LRELU: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_LRELU>, dim3(grid), dim3(512), 0, s, p); break;
             default: hipLaunchKernelGGL(gemm_wreg_kernel<GP_EPI_NONE>, dim3(grid), dim3(512), 0, s, p); break;
+        }
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant == 17) {
+        GP_REQUIRE(wreg_ok && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0, "gp_gemm: variant 17 needs a plain fp16 GEMM with K = 512, N %% 256 == 0, M %% 32 == 0, ldc %% 8 == 0, "
+                   "16-byte aligned C, epilogue none/gelu/relu/lrelu");
+        const int nsl = d->N / 256, tiles = d->M / 32;
+        const int want = gp_num_cus() / nsl > 0 ? gp_num_cus() / nsl : 1;
+        p.tiles_m = cdiv(tiles, want);
+        const int groups = cdiv(tiles, p.tiles_m);
+        const int grid = cdiv(groups * nsl, 8) * 8;
+        switch (d->epilogue) {
+            case GP_EPI_GELU: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_GELU>, dim3(grid), dim3(512), 0, s, p); break;
+            case GP_EPI_RELU: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_RELU>, dim3(grid), dim3(512), 0, s, p); break;
+            case GP_EPI_LRELU: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_LRELU>, dim3(grid), dim3(512), 0, s, p); break;
+            default: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_NONE>, dim3(grid), dim3(512), 0, s, p); break;
         }
         GP_LAUNCH_CHECK("gp_gemm");
     }

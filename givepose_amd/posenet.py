@@ -55,9 +55,9 @@ class PoseNet(nn.Module):
         ONE launch sequence -- every kernel sees G times the rows, the weights pass through the chip once for all of them --
         while the one thing that ties the crops of a batch together, the DCNv3 stride-2 offset / mask prefix (crop b reads
         the rows of crop b // 4 OF ITS BATCH, SURVEY.md 0.3), stays per group.  The results are those of G separate
-        forwards: bit for bit when both runs pick the same GEMM schedules, numerically equivalent (other tiles / split-K at G times
-        the rows: another summation order) otherwise -- tests/test_grouped_launch.py checks both, and every group against the oracle
-        of its batch; bench.py reports the measured difference (overlap_check.grouped_vs_separate_batches)."""
+        forwards up to the summation order (tile choice, split-K factor and GroupNorm chunking follow the row count): numerically
+        equivalent, NOT bitwise -- tests/test_grouped_launch.py bounds the difference over all crops and checks every group against
+        the oracle of its batch; bench.py reports the measured difference (overlap_check.grouped_vs_separate_batches)."""
         super().__init__()
         self.dcn_couple = None if not dcn_couple else int(dcn_couple)
         if split_gemm and dtype != torch.float32:

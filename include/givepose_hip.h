@@ -134,7 +134,8 @@ typedef struct gp_gemm_desc {
     int variant; /* 0 = choose by shape (the product path); otherwise one schedule, for tests and A/B runs: 4 = 128x128 LDS-DMA
                   * tile (the split-K carrier), 5 / 9 = its 4-stage forms, 7 = 128x128 software-pipelined, two workgroups per
                   * CU, 2 / 8 = 256x128, 3 = 256x256, 10 / 11 / 12 = ping-pong 256x256 / 128x256 / 5-stage, 13 = 3x3 window
-                  * conv (Cout 256), 16 = K 512 with the weight slice resident in registers.  + 100 n: timing ablations. */
+                  * conv (Cout 256), 16 / 17 = K 512 with the weight slice resident in registers (17: 16-byte stores, needs ldc % 8 == 0 and a
+                  * 16-byte aligned C; the default of stage-2 fc1).  + 100 n: timing ablations. */
     /* GP_EPI_LNFOLD_GELU only: ln_stats (M, 2, ln_nslab) fp32 partial (sum, sum of squares) of each X row over
      * ln_nslab channel slabs; ln_colsum (N) fp32; ln_eps.  Requires M % 256 == 0, N % 256 == 0, fp16 output. */
     const float* ln_stats;

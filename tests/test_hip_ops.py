@@ -155,11 +155,13 @@ def test_gemm_pingpong_bitwise_vs_plain_schedule(variant):
         assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant), ref)
 
 
-def test_gemm_weights_in_registers_variant():
-    """Variant 16 (K = 512, a 256-row slice of W resident in registers, X streamed in 32-row tiles, GELU in the MFMA
-    shadow, counted vmcnt over DMA + stores): bit-identical to the tile kernels where those run their lean epilogue (same
-    k order per accumulator, same GELU roundings), over repeated launches; fp32 formula on the ragged cases (1, 3, 5
-    tiles per row group, groups of unequal length, padded grid items, ldc > N, no bias); refusals."""
+@pytest.mark.parametrize("variant", [16, 17])
+def test_gemm_weights_in_registers_variant(variant):
+    """Variants 16 / 17 (K = 512, a 256-row slice of W resident in registers, X streamed in 32-row tiles, GELU in the MFMA
+    shadow, counted vmcnt over DMA + stores; 17 = the round-4 form, the default of stage-2 fc1: output channels re-ordered for
+    16-byte stores, DMA lead 2): bit-identical to the tile kernels where those run their lean epilogue (same k order per
+    accumulator, same GELU roundings), over repeated launches; fp32 formula on the ragged cases (1, 3, 5 tiles per row group,
+    groups of unequal length, padded grid items, ldc > N, no bias); refusals."""
     o = ops()
     dt, K = torch.float16, 512
     # tiles per row group T = 16, 2, 1, 1, 1, then 3 / 5 / 7 (prologue, steady state and drain of the counted vmcnt window)
@@ -170,7 +172,7 @@ def test_gemm_weights_in_registers_variant():
         o.gemm(x, w, ref, bias=b, epilogue=epi, variant=8, splitk=1)
         for _ in range(4):
             out = torch.full((M, N), 7.0, dtype=dt, device="cuda")
-            o.gemm(x, w, out, bias=b, epilogue=epi, variant=16, splitk=1)
+            o.gemm(x, w, out, bias=b, epilogue=epi, variant=variant, splitk=1)
             assert torch.equal(out, ref), (M, N, epi)
     for (M, N, epi, bias) in [(32, 256, o.EPI_GELU, True), (96, 256, o.EPI_NONE, False), (160, 512, o.EPI_GELU, True),
                               (4096 + 32, 768, o.EPI_LRELU, True), (33 * 32, 256, o.EPI_RELU, True)]:
@@ -179,13 +181,16 @@ def test_gemm_weights_in_registers_variant():
         lin = x @ w.t() + (b if bias else 0.0)
         ref = {o.EPI_NONE: lin, o.EPI_GELU: F.gelu(lin), o.EPI_RELU: F.relu(lin), o.EPI_LRELU: F.leaky_relu(lin, 0.1)}[epi]
         out = torch.zeros(M, N + 8, dtype=dt, device="cuda")
-        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda() if bias else None, epilogue=epi, variant=16, ldc=N + 8, splitk=1)
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda() if bias else None, epilogue=epi, variant=variant, ldc=N + 8, splitk=1)
         assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, epi)
         assert float(out[:, N:].abs().max()) == 0.0
     x, w = rnd(64, 512, seed=97).to("cuda", dt), rnd(256, 512, seed=98).to("cuda", dt)
     for bad in (dict(x=x[:48], w=w), dict(x=x, w=w[:192]), dict(x=rnd(64, 256, seed=97).to("cuda", dt), w=rnd(256, 256, seed=98).to("cuda", dt))):
-        with pytest.raises(RuntimeError, match="variant 16"):
-            o.gemm(bad["x"], bad["w"], torch.empty(bad["x"].shape[0], bad["w"].shape[0], dtype=dt, device="cuda"), variant=16, splitk=1)
+        with pytest.raises(RuntimeError, match=f"variant {variant}"):
+            o.gemm(bad["x"], bad["w"], torch.empty(bad["x"].shape[0], bad["w"].shape[0], dtype=dt, device="cuda"), variant=variant, splitk=1)
+    if variant == 17:      # 16-byte stores: a row stride that is not a multiple of 8 halfs is refused (variant 0 then picks 16)
+        with pytest.raises(RuntimeError, match="variant 17"):
+            o.gemm(x, w, torch.zeros(64, 260, dtype=dt, device="cuda"), variant=17, ldc=260, splitk=1)
 
 
 def test_gemm_prefetch_hint_changes_nothing():
@@ -195,7 +200,7 @@ def test_gemm_prefetch_hint_changes_nothing():
     dt = torch.float16
     pf_big = torch.zeros(33 * 1024 * 1024 // 2 + 5, dtype=dt, device="cuda")     # 33 MB + 10 bytes
     for pf in (pf_big, pf_big[:500], pf_big[:8], pf_big[:2048 + 4], pf_big[: 2 * 1024 * 1024]):
-        for (M, N, K, variant) in [(4096, 1024, 512, 7), (4096, 1024, 512, 10), (16384, 2048, 512, 16), (2048, 512, 256, 8),
+        for (M, N, K, variant) in [(4096, 1024, 512, 7), (4096, 1024, 512, 10), (16384, 2048, 512, 16), (16384, 2048, 512, 17), (2048, 512, 256, 8),
                                    (1024, 512, 1024, 4), (1000, 260, 128, 5)]:
             x, w, b = rnd(M, K, seed=101).to("cuda", dt), rnd(N, K, seed=102, scale=K ** -0.5).to("cuda", dt), rnd(N, seed=103).cuda()
             ref = torch.empty(M, N, dtype=dt, device="cuda")

@@ -367,12 +367,12 @@ def test_attention_encoder_variant_bs32_matches_oracle(mode, tol):
 
 def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
     """Dispatch guard: at the bench shape the fp16 path must run the schedules DESIGN.md prices -- stage-2 fc1 with its weights
-    in registers (variant 16), the 3x3 head convs on the LDS-window kernel (13), stages 0-1 on the fused MLP -- and the
+    in registers (variant 17), the 3x3 head convs on the LDS-window kernel (13), stages 0-1 on the fused MLP -- and the
     split-operand mode their split forms.  (Round 3 once lost variant 16 to an if / else slip: -5 % end to end, no test noticed.)"""
     from givepose_amd import PoseNet, PoseNetConfig
     lab = _launch_labels(net16, _batch(64, 3))
     n = lambda key: sum(v for l, v in lab.items() if key in l)
-    assert n("gemm v16 M16384 N2048 K512 epi1") == 27, lab
+    assert n("gemm v17 M16384 N2048 K512 epi1") == 27, lab
     assert n("conv3x3 s1 v13 64x64") == 4 and n("conv3x3 s1 v13 32x32") == 4, lab
     assert n("convnext_mlp C128") == 3 and n("convnext_mlp C256") == 3, lab
     assert n("N512 K2048 epi4") == 27, lab
