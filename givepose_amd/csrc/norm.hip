@@ -306,16 +306,23 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
 }
 
 // ---------------------------------------------------------------------------- dw7x7 + LN on the matrix cores (fp16)
-// The tiled kernel above is VALU bound (49 taps x 8 channels of v_fma_mix per pixel-thread).  A depthwise filter is
-// a block-diagonal matrix product: for a group of 16 channels and two taps (kh, kw), (kh+1, kw)
-//     D[n][m] += sum_{k=(tap j, channel c)} A[n][k] * B[k][m],  A[n][(j, c)] = (c == n) ? w[tap j][n] : 0,
-//     B[(j, c)][m] = in[pixel m shifted by tap j][c]
-// is one v_mfma_f32_16x16x32_f16 over 16 output pixels of one row.  1/16 of the MACs are useful, which still beats
-// the VALU by ~3x, and the B fragment is a single conflict-free ds_read_b128 of the halo tile: bits 1-3 of a pixel's
-// 16-byte slot index are XOR-ed with its halo column, bit 0 (the channel half, = lane bit 4) stays, which keeps the
-// 16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) on 16 different slots for all 7 shifts.  A wave owns one 16-channel group per 128-channel slab and keeps the
-// 28 A fragments (4 row pairs x 7 kw) in registers; a B fragment (rows r, r+1) is shared by the output rows t and
-// t+2 (tap pairs kp and kp-1).  Output tile 16 x 4 pixels, slabs double-buffered by LDS-DMA as above.
+// The tiled kernel above is VALU bound (49 taps x 8 channels of v_fma_mix per pixel-thread).  A depth-wise filter is a
+// block-diagonal matrix product, and the block structure is a free choice.  Round 1-3: one output row, 16 channels per MFMA
+//     D[c][px] += sum_{(tap j, c')} A[c][(j, c')] B[(j, c')][px],  A = diag over c of w[tap j][c],  two taps (kh, kh + 1) per MFMA
+// -- 1/16 of the MACs useful, 3.5 MFMAs per output row of 16 channels x 16 pixels.  Round 4 (this form): TWO output rows x
+// EIGHT channels per MFMA and a K block of FOUR input rows x 8 channels,
+//     D[(r, c)][px] += sum_{(i, c')} A[(r, c)][(i, c')] B[(i, c')][px],   A[(r, c)][(i, c')] = (c == c') w[kh = i + 4 blk - r][kw][c]
+//     (zero where kh is outside 0..6),  B[(i, c')][px] = in[row 2 p + 4 blk + i][px + kw][c'],
+// i.e. a banded (Toeplitz over the rows) x diagonal (over the channels) A: the output rows 2p, 2p + 1 need the input rows
+// 2p .. 2p + 7 = exactly two K blocks, 14 of whose 16 (r, i) pairs carry a tap.  Two MFMAs per row PAIR of 8 channels x 16
+// pixels = 2 per output row of 16 channels, against 3.5: 0.57 of the matrix-pipe time, which is what bounds these kernels once
+// their traffic is on chip (C = 128 at 64 x 64: 57 us of MFMA issue per launch of 128 crops in the old form).
+// A lane of a B fragment reads ONE 16-byte slot (8 channels of one pixel of one input row: lane = (pixel n, row i)); bits 1-3 of
+// a pixel's slot index are XOR-ed with its halo column and bit 0 with its halo ROW parity, so that the lanes of every
+// ds_read_b128 lane group ({0-3,12-15,20-27}, ...: two input rows of opposite parity, eight column residues each) hit 16
+// different slots for all 7 column shifts.  An A fragment is one non-zero half per lane, built from the tap table in LDS.
+// A wave owns 16 channels (two octets) per 128-channel slab; output tile 16 x 4 pixels (two row pairs), slabs by LDS-DMA
+// (double-buffered for C = 512 on small grids, single-buffered at two workgroups per CU otherwise).
 // RAW = true: one workgroup per (tile, 128-channel slab) (blockIdx.y = slab), no LayerNorm: y gets the conv + bias
 // output rounded to fp16 and `stats` (pixel, {sum, sum of squares}, slab) the per-pixel partial moments of those
 // ROUNDED values over the slab's channels; the LayerNorm is applied by the consuming GEMM's epilogue
@@ -339,8 +346,8 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
     const int par_bytes = ((3 * C * 4 + 1023) / 1024) * 1024;
     const float* par_s = reinterpret_cast<const float*>(dsm + NBUF * BUF);
-    float* red_s = reinterpret_cast<float*>(dsm + NBUF * BUF + par_bytes);   // [8 waves][64 px]
-    float* stat_s = red_s + 8 * 64;                                          // [64 px]
+    float* red_s = reinterpret_cast<float*>(dsm + NBUF * BUF + par_bytes);   // [8 waves][64 px] (+ the same again for the squares)
+    float* stat_s = red_s + 8 * 64;                                          // RAW: [64 px] + the squares' partials behind it
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         const int i = ins * 64 + lane, px = i >> 4, ps = i & 15;
         const int iy = px / IW, ix = px - iy * IW;
         const int gy = h0 - R + iy, gx = w0 - R + ix;
-        const int ls = ps ^ ((ix & 7) << 1);
+        const int ls = ps ^ ((ix & 7) << 1) ^ (iy & 1);
         const bool ok = ins < IN_INSTR && px < NPX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         xsrc0[j] = ok ? xb + ((long)gy * W + gx) * C + slab0 * 128 + ls * 8 : zero;
         if (ok) xok |= 1u << j;
@@ -394,28 +401,36 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     }
     if (dbg != 6) issue(0, 0);
 
-    // lane roles: A row / D channel-quad n4, B column / D pixel m, k-chunk q (tap j = q>>1, channel half q&1)
-    const int m = lane & 15, q = lane >> 4, jt = q >> 1;
-    const int lslot = wave * 2 + (q & 1);
-    unsigned sw[7];   // byte offset of this lane's B chunk for shift kw, row 0 (+ the second tap's row)
+    // lane roles.  B / D column: output pixel n of the row; q = lane >> 4: as a B lane the input row of the K block, as a D lane
+    // the rows 4q .. 4q + 3 of D = output row 2p + (q >> 1), channels 8 o + 4 (q & 1) .. + 4 of the wave's octet o.  As an A
+    // lane: row (ar, ac) = (output row of the pair, channel of the octet) = (n >> 3, n & 7), K chunk q = input row of the block.
+    const int n = lane & 15, q = lane >> 4;
+    const int ar = n >> 3, ac = n & 7;
+    unsigned sw[7];   // byte offset of this lane's B slot (octet 0; octet 1 = ^ 16) for shift kw, halo row q
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw)
-        sw[kw] = (m + kw) * 256 + ((lslot ^ (((m + kw) & 7) << 1)) << 4) + jt * ROWB;
-    const int pos = m & 7;
-    const bool a_lane = (q & 1) == (m >> 3);
-    unsigned mk[4], mk3[4];
+        sw[kw] = q * ROWB + (n + kw) * 256 + ((((wave * 2) ^ (((n + kw) & 7) << 1)) ^ (q & 1)) << 4);
+    // tap row of this A lane: kh = q - ar (K block 0, valid from 0 up) / q + 4 - ar (block 1, valid up to 6); an invalid lane reads a
+    // clamped tap and is masked to zero.  The lane's one non-zero half sits in dword ac >> 1, half ac & 1.
+    const int kh0 = q - ar, kh1 = q + 4 - ar;
+    const unsigned woff0 = (unsigned)((kh0 < 0 ? 0 : kh0) * 7 * 256 + (wave * 16 + ac) * 2);
+    const unsigned woff1 = (unsigned)((kh1 > 6 ? 6 : kh1) * 7 * 256 + (wave * 16 + ac) * 2);
+    unsigned mk0[4], mk1[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        mk[v] = (a_lane && v == (pos >> 1)) ? 0xffffffffu : 0u;
-        mk3[v] = jt ? 0u : mk[v];
+        mk0[v] = (kh0 >= 0 && v == (ac >> 1)) ? 0xffffffffu : 0u;
+        mk1[v] = (kh1 <= 6 && v == (ac >> 1)) ? 0xffffffffu : 0u;
     }
-    const int sh = 16 * (pos & 1);
+    const int sh = 16 * (ac & 1);
+    constexpr int NP = TH / 2;   // output row pairs of the tile
 
-    f32x4 acc[NSLAB][TH];
+    f32x4 acc[NSLAB][NP][2];    // [slab][row pair][octet]
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
-        for (int t = 0; t < TH; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc[s][pp][o] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
@@ -425,29 +440,30 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         const char* in_s = dsm + (s & (NBUF - 1)) * BUF;
         const char* w_s = in_s + IN_INSTR * 1024;
         union Frag { uint4 u; half8 h; };
-        // software pipeline over the 7 column shifts: the 4 A fragments and 10 B rows of shift kw+1 are fetched
-        // while the 16 MFMAs of shift kw run.  Rows r, r+1 of the halo tile feed output row t with tap pair kp
-        // whenever t + 2 kp == r.  Row 10 (only met with the all-zero half of the kp == 3 fragment) lies in the tap
-        // area behind the tile: finite data.
-        Frag af[PIPE ? 2 : 1][4], bf[PIPE ? 2 : 1][TH + 6];
-        unsigned wraw[4];
+        // software pipeline over the 7 column shifts (PIPE): the 4 tap words and 4 NP B fragments of shift kw+1 are fetched
+        // while the 4 NP MFMAs of shift kw run.  Fragment (pp, blk, o): halo rows 2 pp + 4 blk .. + 4 (lane: + q), octet o.
+        Frag af[PIPE ? 2 : 1][2][2], bf[PIPE ? 2 : 1][NP][2][2];    // af[..][blk][o], bf[..][pp][blk][o]
+        unsigned wraw[2][2];
         auto fetch = [&](int kw, int slot) {   // LDS reads only: the VALU part (build) must not sit in front of the MFMAs
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) {
-                const int kh = 2 * kp + jt;
-                const int tap = (kh < 7 ? kh : 6) * 7 + kw;
-                wraw[kp] = *reinterpret_cast<const unsigned short*>(w_s + tap * 256 + (wave * 16 + m) * 2);
+            for (int o = 0; o < 2; ++o) {
+                wraw[0][o] = *reinterpret_cast<const unsigned short*>(w_s + woff0 + kw * 256 + o * 16);
+                wraw[1][o] = *reinterpret_cast<const unsigned short*>(w_s + woff1 + kw * 256 + o * 16);
             }
 #pragma unroll
-            for (int r = 0; r < TH + 6; ++r)
-                bf[slot][r].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + r * ROWB);
+            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        bf[slot][pp][blk][o].u = *reinterpret_cast<const uint4*>(in_s + (sw[kw] ^ (o << 4)) + (2 * pp + 4 * blk) * ROWB);
         };
         auto build = [&](int slot) {
 #pragma unroll
-            for (int kp = 0; kp < 4; ++kp) {
-                const unsigned u = wraw[kp] << sh;
-                af[slot][kp].u = kp == 3 ? uint4{u & mk3[0], u & mk3[1], u & mk3[2], u & mk3[3]}
-                                         : uint4{u & mk[0], u & mk[1], u & mk[2], u & mk[3]};
+            for (int o = 0; o < 2; ++o) {
+                const unsigned u0 = wraw[0][o] << sh, u1 = wraw[1][o] << sh;
+                af[slot][0][o].u = uint4{u0 & mk0[0], u0 & mk0[1], u0 & mk0[2], u0 & mk0[3]};
+                af[slot][1][o].u = uint4{u1 & mk1[0], u1 & mk1[1], u1 & mk1[2], u1 & mk1[3]};
             }
         };
         if (PIPE) { fetch(0, 0); build(0); }
@@ -457,13 +473,12 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
             else if (kw + 1 < 7) fetch(kw + 1, (kw + 1) & 1);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < TH + 6; ++r)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int kp = 0; kp < 4; ++kp) {
-                    const int t = r - 2 * kp;
-                    if (t >= 0 && t < TH)
-                        acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[PIPE ? kw & 1 : 0][kp].h, bf[PIPE ? kw & 1 : 0][r].h, acc[s][t], 0, 0, 0);
-                }
+                for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+                        acc[s][pp][o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[PIPE ? kw & 1 : 0][blk][o].h, bf[PIPE ? kw & 1 : 0][pp][blk][o].h, acc[s][pp][o], 0, 0, 0);
             if (PIPE) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kw + 1 < 7) build((kw + 1) & 1);
@@ -475,32 +490,37 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         }
     }
 
-    // D layout: lane holds channels cbase + 4 q + {0..3} of pixel (t, m).  Bias, then LayerNorm over C.
-    const int cq = wave * 16 + q * 4;
+    // D layout: lane (n, q) holds, of slab s, row pair pp and octet o, the channels s 128 + wave 16 + 8 o + 4 (q & 1) + {0..3} of
+    // pixel (row 2 pp + (q >> 1), n).  Bias, then LayerNorm over C.
+    const int rsel = q >> 1;
+    const int cq = wave * 16 + (q & 1) * 4;      // + 8 o
 #pragma unroll
-    for (int s = 0; s < NSLAB; ++s) {
-        const float4 bv = *reinterpret_cast<const float4*>(par_s + (slab0 + s) * 128 + cq);
+    for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
-        for (int t = 0; t < TH; ++t) {
-            acc[s][t][0] += bv.x; acc[s][t][1] += bv.y; acc[s][t][2] += bv.z; acc[s][t][3] += bv.w;
+        for (int o = 0; o < 2; ++o) {
+            const float4 bv = *reinterpret_cast<const float4*>(par_s + (slab0 + s) * 128 + cq + o * 8);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                acc[s][pp][o][0] += bv.x; acc[s][pp][o][1] += bv.y; acc[s][pp][o][2] += bv.z; acc[s][pp][o][3] += bv.w;
+            }
         }
-    }
     if constexpr (RAW) {
         float* red2_s = stat_s + 64;                 // [8 waves][64 px] sums of squares
-        half4 o[TH];
+        half4 ov[NP][2];
 #pragma unroll
-        for (int t = 0; t < TH; ++t) {
+        for (int pp = 0; pp < NP; ++pp) {
             float a = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[t][e] = (_Float16)acc[0][t][e];
-                const float f = (float)o[t][e];
-                a += f;
-                a2 += f * f;
-            }
-            a += __shfl_xor(a, 16); a2 += __shfl_xor(a2, 16);
-            a += __shfl_xor(a, 32); a2 += __shfl_xor(a2, 32);
-            if (q == 0) { red_s[wave * 64 + t * 16 + m] = a; red2_s[wave * 64 + t * 16 + m] = a2; }
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ov[pp][o][e] = (_Float16)acc[0][pp][o][e];
+                    const float f = (float)ov[pp][o][e];
+                    a += f;
+                    a2 += f * f;
+                }
+            a += __shfl_xor(a, 16); a2 += __shfl_xor(a2, 16);      // the other channel quad of the octets (q ^ 1)
+            if ((q & 1) == 0) { const int px = (2 * pp + rsel) * 16 + n; red_s[wave * 64 + px] = a; red2_s[wave * 64 + px] = a2; }
         }
         __syncthreads();   // also: every wave is done reading the halo tile, which the output tile overlays
         const int nsl = C >> 7;
@@ -514,10 +534,11 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
             stats[(pixel * 2 + which) * nsl + slab0] = a;
         }
         char* out_r = dsm;
-        const int chunk = wave * 2 + (q >> 1);
 #pragma unroll
-        for (int t = 0; t < TH; ++t)
-            *reinterpret_cast<half4*>(out_r + (t * 16 + m) * 256 + ((chunk ^ m) << 4) + (q & 1) * 8) = o[t];
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+                *reinterpret_cast<half4*>(out_r + ((2 * pp + rsel) * 16 + n) * 256 + (((wave * 2 + o) ^ n) << 4) + (q & 1) * 8) = ov[pp][o];
         __syncthreads();
         for (int i = tid; i < 64 * 16; i += 512) {
             const int px = i >> 4, c = i & 15;
@@ -526,57 +547,60 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         }
         return;
     }
+    // LayerNorm statistics in ONE round: per-wave partial (sum, sum of squares) of every pixel -> LDS, one barrier, then every
+    // lane adds the eight partials of ITS pixels itself (broadcast reads).  var = E[x^2] - mean^2 in fp32: the conv outputs have
+    // |mean| of the order of their spread, so the subtraction costs a few of fp32's 24 bits -- nothing at fp16 output precision.
+    // (Until round 4: two passes (mean, then centred squares), each with a 64-thread reduction stage = four barriers per tile;
+    // the tile is 64 pixels and the kernel is made of such fixed costs: scripts/dw_ablate.py.)
     const float invC = 1.0f / C;
-    float mean[TH], rstd[TH];
+    float mean[NP], rstd[NP];
+    float* red2_s = red_s + 8 * 64;              // [8 waves][64 px] sums of squares (behind the sums: launch_dw7_mfma sizes both)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pp = 0; pp < NP; ++pp) {
+        float a = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int t = 0; t < TH; ++t) {
-            float a = 0.f;
+        for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
-            for (int s = 0; s < NSLAB; ++s)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (pass == 1) acc[s][t][e] -= mean[t];
-                    a += pass == 0 ? acc[s][t][e] : acc[s][t][e] * acc[s][t][e];
+                    a += acc[s][pp][o][e];
+                    a2 += acc[s][pp][o][e] * acc[s][pp][o][e];
                 }
-            a += __shfl_xor(a, 16);
-            a += __shfl_xor(a, 32);
-            if (q == 0) red_s[wave * 64 + t * 16 + m] = a;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            float a = 0.f;
+        a += __shfl_xor(a, 16);
+        a2 += __shfl_xor(a2, 16);
+        if ((q & 1) == 0) { red_s[wave * 64 + (2 * pp + rsel) * 16 + n] = a; red2_s[wave * 64 + (2 * pp + rsel) * 16 + n] = a2; }
+    }
+    __syncthreads();
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) a += red_s[w8 * 64 + tid];
-            stat_s[tid] = pass == 0 ? a * invC : rsqrtf(a * invC + eps);
-        }
-        __syncthreads();
+    for (int pp = 0; pp < NP; ++pp) {
+        float a = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int t = 0; t < TH; ++t) {
-            if (pass == 0) mean[t] = stat_s[t * 16 + m];
-            else rstd[t] = stat_s[t * 16 + m];
-        }
+        for (int w8 = 0; w8 < 8; ++w8) { a += red_s[w8 * 64 + (2 * pp + rsel) * 16 + n]; a2 += red2_s[w8 * 64 + (2 * pp + rsel) * 16 + n]; }
+        mean[pp] = a * invC;
+        rstd[pp] = rsqrtf(fmaxf(a2 * invC - mean[pp] * mean[pp], 0.f) + eps);
     }
     // normalised rows go through LDS (the DMA buffers are free now) so that the global stores are 16 B per lane and
     // 1 KB contiguous per pixel; 16-byte chunks of a pixel are XOR-swizzled with the pixel index.
     char* out_s = dsm;
 #pragma unroll
-    for (int s = 0; s < NSLAB; ++s) {
-        const float4 gw = *reinterpret_cast<const float4*>(par_s + C + s * 128 + cq);
-        const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 128 + cq);
-        const int chunk = s * 16 + wave * 2 + (q >> 1);
+    for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
-        for (int t = 0; t < TH; ++t) {
-            half4 o;
-            o[0] = (_Float16)(acc[s][t][0] * rstd[t] * gw.x + gb.x);
-            o[1] = (_Float16)(acc[s][t][1] * rstd[t] * gw.y + gb.y);
-            o[2] = (_Float16)(acc[s][t][2] * rstd[t] * gw.z + gb.z);
-            o[3] = (_Float16)(acc[s][t][3] * rstd[t] * gw.w + gb.w);
-            const int px = t * 16 + m;
-            *reinterpret_cast<half4*>(out_s + px * (C * 2) + ((chunk ^ m) << 4) + (q & 1) * 8) = o;
+        for (int o = 0; o < 2; ++o) {
+            const float4 gw = *reinterpret_cast<const float4*>(par_s + C + s * 128 + cq + o * 8);
+            const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 128 + cq + o * 8);
+            const int chunk = s * 16 + wave * 2 + o;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                half4 ov;
+                ov[0] = (_Float16)((acc[s][pp][o][0] - mean[pp]) * rstd[pp] * gw.x + gb.x);
+                ov[1] = (_Float16)((acc[s][pp][o][1] - mean[pp]) * rstd[pp] * gw.y + gb.y);
+                ov[2] = (_Float16)((acc[s][pp][o][2] - mean[pp]) * rstd[pp] * gw.z + gb.z);
+                ov[3] = (_Float16)((acc[s][pp][o][3] - mean[pp]) * rstd[pp] * gw.w + gb.w);
+                const int px = (2 * pp + rsel) * 16 + n;
+                *reinterpret_cast<half4*>(out_s + px * (C * 2) + ((chunk ^ n) << 4) + (q & 1) * 8) = ov;
+            }
         }
-    }
     __syncthreads();
     const int cpp = C / 8;   // 16-byte chunks per pixel
     for (int i = tid; i < 64 * cpp; i += 512) {
@@ -591,7 +615,7 @@ template <int NSLAB, int NBUF>
 void launch_dw7_mfma(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B,
                      int H, int W, int C, float eps, hipStream_t s, int dbg) {
     constexpr int NPX = 22 * 10, IN_INSTR = (NPX * 16 + 63) / 64, W_INSTR = (49 * 16 + 63) / 64;
-    const int LDS = NBUF * (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024 + 9 * 64 * 4;
+    const int LDS = NBUF * (IN_INSTR + W_INSTR) * 1024 + ((3 * C * 4 + 1023) / 1024) * 1024 + 16 * 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)dwconv7_ln_mfma_kernel<NSLAB, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
