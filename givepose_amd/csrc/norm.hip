@@ -323,6 +323,11 @@ void launch_dw7_tiled(const void* x, const void* wt, const float* bias, const fl
 // different slots for all 7 column shifts.  An A fragment is one non-zero half per lane, built from the tap table in LDS.
 // A wave owns 16 channels (two octets) per 128-channel slab; output tile 16 x 4 pixels (two row pairs), slabs by LDS-DMA
 // (double-buffered for C = 512 on small grids, single-buffered at two workgroups per CU otherwise).
+// What bounds it (scripts/dw_ablate.py, profiles/r04_dw_*): not the matrix pipe any more -- with the conv loop AND the halo DMA
+// removed the kernel keeps 50-55 % of its time, and a PERSISTENT form (one workgroup per CU walking a run of tiles, taps and
+// parameters resident, the next item's halo landing while this one is convolved / normalised / stored; built, bitwise equal,
+// profiles/r04_dw_persistent_ab.txt, removed again) ran no faster than two one-tile workgroups per CU: 55 KB of halo in flight per
+// CU against ~2 us of memory latency is what sets the pace (13-18 GB/s per CU), not launch or index overheads.
 // RAW = true: one workgroup per (tile, 128-channel slab) (blockIdx.y = slab), no LayerNorm: y gets the conv + bias
 // output rounded to fp16 and `stats` (pixel, {sum, sum of squares}, slab) the per-pixel partial moments of those
 // ROUNDED values over the slab's channels; the LayerNorm is applied by the consuming GEMM's epilogue
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
             glds16_n(src, lds0 + NBUF * BUF + ins * 1024);
         }
     }
-    if (dbg != 6) issue(0, 0);
+    if (dbg != 6 && dbg != 8) issue(0, 0);
 
     // lane roles.  B / D column: output pixel n of the row; q = lane >> 4: as a B lane the input row of the K block, as a D lane
     // the rows 4q .. 4q + 3 of D = output row 2p + (q >> 1), channels 8 o + 4 (q & 1) .. + 4 of the wave's octet o.  As an A
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
     for (int s = 0; s < NSLAB; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (NBUF == 2 && s + 1 < NSLAB && dbg != 6) issue(s + 1, (s + 1) & 1);
+        if (NBUF == 2 && s + 1 < NSLAB && dbg != 6 && dbg != 8) issue(s + 1, (s + 1) & 1);
         const char* in_s = dsm + (s & (NBUF - 1)) * BUF;
         const char* w_s = in_s + IN_INSTR * 1024;
         union Frag { uint4 u; half8 h; };
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         };
         if (PIPE) { fetch(0, 0); build(0); }
 #pragma unroll
-        for (int kw = 0; kw < (dbg == 5 ? 0 : 7); ++kw) {
+        for (int kw = 0; kw < (dbg == 5 || dbg == 8 || dbg == 9 ? 0 : 7); ++kw) {   // timing ablations: 5 no conv, 6 no halo DMA, 8 neither, 9 no conv + no output
             if (!PIPE) { fetch(kw, 0); build(0); }
             else if (kw + 1 < 7) fetch(kw + 1, (kw + 1) & 1);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         }
         if (NBUF == 1 && s + 1 < NSLAB) {
             __syncthreads();
-            if (dbg != 6) issue(s + 1, 0);
+            if (dbg != 6 && dbg != 8) issue(s + 1, 0);
         }
     }
 
@@ -607,7 +612,8 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         const int px = i / cpp, c = i - px * cpp;
         const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
         const int t = px >> 4, mm = px & 15;
-        *reinterpret_cast<uint4*>(y + (((long)b * H + h0 + t) * W + w0 + mm) * C + c * 8) = v;
+        if (dbg != 9 || v.x == 0x12345678u)
+            *reinterpret_cast<uint4*>(y + (((long)b * H + h0 + t) * W + w0 + mm) * C + c * 8) = v;
     }
 }
 

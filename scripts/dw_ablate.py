@@ -1,5 +1,5 @@
 """Timing ablations of the MFMA depth-wise 7x7 + LayerNorm kernel (gp_dwconv_ln act codes 105 = no conv loop, 106 = no LDS-DMA of the
-halo tiles; wrong results) at the bench shapes, B = 64 and 128 crops; interleaved rounds, medians."""
+halo tiles, 108 = neither, 109 = no conv and no global stores; wrong results) at the bench shapes, B = 64 and 128 crops; interleaved rounds, medians."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +12,7 @@ for B in (64, 128):
         y = torch.empty_like(x)
         res = {}
         for rnd in range(5):
-            for act, name in ((0, "full"), (105, "no conv loop"), (106, "no halo DMA"), (104, "LDS-tiled VALU kernel")):
+            for act, name in ((0, "full"), (105, "no conv loop"), (106, "no halo DMA"), (108, "no conv, no halo DMA"), (109, "no conv, no global stores")):
                 f = lambda: ops.dwconv_ln(x, w, b, lw, lb, y, 7, act=act)
                 for _ in range(3): f()
                 torch.cuda.synchronize()
