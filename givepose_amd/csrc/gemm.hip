@@ -922,7 +922,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {   // as wait_vmcnt for cou
 // SPL (split-operand mode, GemmKP::split_n1): the (chunk, tap) loop runs three times -- X_hi windows against W_lo' rows, X_lo'
 // against W_hi, then (accumulators scaled by 2^-S) X_hi against W_hi -- as one stream of 3 * NCC chunks through the same W
 // ring and window double buffer; fp32 output through the generic epilogue.
-template <int WIMG, int NS, bool SPL = false>
+template <int WIMG, int NS, bool SPL = false, bool GNL = false>    // GNL: measurement arm (GroupNorm-apply + GELU in the loader), see below
 __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     constexpr int MT = 8, NT = 4, BM = 256, BN = 256, LEAD = NS - 2;
     // window row pitch WW: a multiple of 8 pixels, so that a kh shift never changes bit 2 of the window pixel index
@@ -1066,6 +1066,25 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             }
             const bool wi = st + LEAD < NSTG && p.dbg != 1;
             if (wi) stage_w(wbuf, cc + (tap + LEAD) / 9, (tap + LEAD) % 9);
+            if (GNL && tap >= 2 && tap <= 5) {
+                // MEASUREMENT ARM (wrong results; scripts/conv_gn_loader_ab.py, profiles/r04_conv_gn_loader_ab.txt): what GroupNorm-apply +
+                // GELU inside the window loader would cost at the least.  The window piece this wave requested at tap - 1 has landed (the
+                // counted wait of the previous load phase covers it): one pass over the wave's OWN piece in LDS -- read 16 bytes per lane,
+                // scale / shift / GELU eight values, write back -- in the load phase, where it would have to live.  (A real version adds
+                // the per-(image, channel) table look-up and the border mask on top.)
+                const int j = tap - 2;
+                if (cc + 1 < NG && wave + 8 * j < NI) {
+                    char* a = smem + WIN0 + ((cc + 1) & 1) * WINB + (wave + 8 * j) * 1024 + lane * 16;
+                    half8 h = *reinterpret_cast<half8*>(a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {      // one 2-vector at a time: the kernel has no registers to spare
+                        f32x2 f = f32x2{fmaf((float)h[2 * e], p.split_scale, 0.25f), fmaf((float)h[2 * e + 1], p.split_scale, 0.25f)};
+                        f = gelu_poly2(f);
+                        h[2 * e] = (half_t)f[0]; h[2 * e + 1] = (half_t)f[1];
+                    }
+                    *reinterpret_cast<half8*>(a) = h;
+                }
+            }
             // the own W rows of step st + 1 have landed once at most the ops issued after them are outstanding: those of
             // this phase and (LEAD = 3) of the previous one (vmcnt retires in issue order, the window pieces included)
             const int ops0 = (wi ? 2 : 0) + (xi ? 1 : 0);
@@ -1775,6 +1794,10 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((conv3_pp_kernel<16, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
         }
+#ifdef GP_CONV_GNL   // investigation build only (GP_EXTRA_HIPCC_FLAGS=-DGP_CONV_GNL GP_BUILD_TAG=gnl): the arm spills 28 registers -- scratch is banned in the product
+        else if (d->Win == 64 && p.dbg == 7) hipLaunchKernelGGL((conv3_pp_kernel<64, 4, false, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
+        else if (d->Win == 32 && p.dbg == 7) hipLaunchKernelGGL((conv3_pp_kernel<32, 4, false, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
+#endif
         else if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3_pp_kernel<16, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
