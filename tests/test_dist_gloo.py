@@ -54,3 +54,27 @@ def test_shard_bounds_cover_and_order():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_checkpoint_key_report(tmp_path):
+    """load_checkpoint(report_path=...): the full rename / unknown / missing report is written BEFORE a strict load fails, so that the
+    first user with the released weights can send back one file that settles the timm key layout."""
+    import json
+    import torch
+    from givepose_amd import PoseNet
+    from givepose_amd.checkpoint import load_checkpoint
+    net = PoseNet()
+    sd = net.state_dict()
+    some = list(sd)[:6]
+    ck = {("module." + k): sd[k] for k in some}                       # a DataParallel checkpoint: renamed
+    ck["backbone.not_a_layer.weight"] = torch.zeros(3, 5)             # ... with a key that matches nothing
+    rep = tmp_path / "keys.json"
+    import pytest
+    with pytest.raises(KeyError, match="match no tensor"):
+        load_checkpoint(net, ck, verbose=False, report_path=str(rep))
+    doc = json.load(open(rep))
+    assert len(doc["renamed"]) == 6 and doc["renamed"][0]["checkpoint"].startswith("module.")
+    assert doc["unknown"] == [{"checkpoint": "backbone.not_a_layer.weight", "shape": [3, 5]}]
+    assert len(doc["missing"]) == len(sd) - 6 and doc["shape_mismatch"] == []
+    out = load_checkpoint(net, {("module." + k): sd[k] for k in some}, verbose=False, report_path=str(rep))
+    assert len(out["renamed"]) == 6 and json.load(open(rep))["unknown"] == []
