@@ -11,7 +11,7 @@ requests at 64 B, i.e. reads exactly half of a wide coalesced stream -> doubled 
 """
 import collections, csv, glob, json, sys
 
-CLASS = (("gemm", ("gemm_big_kernel", "gemm_wreg_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
+CLASS = (("gemm", ("gemm_big_kernel", "gemm_wreg_kernel", "gemm_wreg2_kernel", "splitk_reduce", "convnext_mlp_kernel", "conv3_pp_kernel")), ("dcnv3", ("dcnv3_",)),
          ("dwconv_ln", ("dwconv",)), ("norm", ("gn_", "layernorm")),
          ("elementwise", ("upsample", "col2im", "pointwise_k3", "mask_resize")),
          ("small", ("stem_", "xyz_out", "smallcin", "size_", "pose_tail")))
@@ -59,7 +59,7 @@ if len(sys.argv) > 6:
                                        "note": "FETCH_SIZE factor measured by scripts/pmc_calib.hip for 128-byte rows read by 16 lanes x 8 B"}
     except Exception as e:
         calib = {"error": repr(e)}
-json.dump({"commit": commit, "batches_per_launch": int(sys.argv[7]) if len(sys.argv) > 7 else 1, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-graph --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-check --no-serial --inflight 1 (scripts/profile_r03.sh), bs=64 fp16; hbm_bytes_per_step = per batch of 64 crops",
+json.dump({"commit": commit, "batches_per_launch": int(sys.argv[7]) if len(sys.argv) > 7 else 1, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-graph --no-roofline --no-cpu-baseline --no-parity --no-h2d --no-check --no-serial --inflight 1 (scripts/profile_r0N.sh), bs=64 fp16; hbm_bytes_per_step = per batch of 64 crops",
            "correction": "FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B); counters in KB", "calibration": calib, "classes": res},
           open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))
