@@ -922,13 +922,20 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {   // as wait_vmcnt for cou
 // SPL (split-operand mode, GemmKP::split_n1): the (chunk, tap) loop runs three times -- X_hi windows against W_lo' rows, X_lo'
 // against W_hi, then (accumulators scaled by 2^-S) X_hi against W_hi -- as one stream of 3 * NCC chunks through the same W
 // ring and window double buffer; fp32 output through the generic epilogue.
-template <int WIMG, int NS, bool SPL = false, bool GNL = false>    // GNL: measurement arm (GroupNorm-apply + GELU in the loader), see below
+// WIDE (round 4): a tile of 512 pixels x 128 output channels instead of 256 x 256 -- the same MFMAs, fragment reads and LDS per
+// workgroup, but per K step ONE W piece per wave instead of two and 1 MB instead of 1.37 MB of LDS-DMA per tile (the W rows of a
+// step are 8 KB, the window of a chunk 45 KB): the load phase of the ping-pong schedule, which is what bounds the kernel, carries
+// a third fewer LDS-DMA instructions.  Two workgroups (the two channel halves) share a pixel tile's window through the XCD's L2.
+template <int WIMG, int NS, bool SPL = false, bool GNL = false, bool WIDE = false>    // GNL: measurement arm (GroupNorm-apply + GELU in the loader), see below
 __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
-    constexpr int MT = 8, NT = 4, BM = 256, BN = 256, LEAD = NS - 2;
+    constexpr int MT = 8, NT = 4, BM = WIDE ? 512 : 256, BN = WIDE ? 128 : 256, LEAD = NS - 2;
+    constexpr int NTN = 256 / BN, WPI = BN / 128;       // channel tiles per pixel tile; W pieces (1 KB) per wave and K step
+    static_assert(!WIDE || (WIMG >= 32 && !SPL), "wide tile: whole rows of ONE image (W >= 32), fp16 mode");
     // window row pitch WW: a multiple of 8 pixels, so that a kh shift never changes bit 2 of the window pixel index
     // (the swizzle bit) and the nine tap addresses of an m-tile are 3 registers (one per kw) + an immediate offset
     constexpr int TR = BM / WIMG, WW = (WIMG + 2 + 7) / 8 * 8, NP = (TR + 2) * WW, NI = (NP + 15) / 16;
-    constexpr int WINB = 32768, WST = BN * 64;     // two window buffers, 32 KB apart
+    constexpr int WINB = WIDE ? 49152 : 32768, WST = BN * 64;     // two window buffers
+    constexpr int XJ = (NI + 7) / 8;                // window pieces per wave and chunk
     static_assert(NI * 1024 <= WINB, "window");
     constexpr int WIN0 = NS * WST;
     constexpr int SMEM = WIN0 + 2 * WINB;
@@ -937,14 +944,14 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1, grp = wave >> 2;
+    const int wm = WIDE ? (wave & 3) : (wave & 1), wn = WIDE ? (wave >> 2) : (wave >> 1), grp = wave >> 2;
     const int fr = lane & 15, fq = lane >> 4;
 
-    const int nblk = p.tiles_m;
+    const int nblk = p.tiles_m * NTN;
     const int bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int m0 = tile * BM;
+    const int m0 = (tile / NTN) * BM, n0 = (tile % NTN) * BN;
     const int img = m0 / (p.H * WIMG), h0 = (m0 - img * p.H * WIMG) / WIMG;
     const int Cin = p.Cin, NCC = Cin >> 5, NG = SPL ? 3 * NCC : NCC, NSTG = 9 * NG;   // NG chunks of 32 channels in all
 
@@ -955,17 +962,17 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     // ---- DMA sources
     const int lrow = lane >> 2;
     const int wchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
-    unsigned woff[2];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
+    unsigned woff[WPI];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
 #pragma unroll
-    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)((((i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
+    for (int i = 0; i < WPI; ++i) woff[i] = (unsigned)(((n0 + (i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3.  32-bit byte offsets from the
     // image base (scalar); halo / border lanes point at the zero page instead (xvalid)
-    unsigned xoff[4];
+    unsigned xoff[XJ];
     unsigned xvalid = 0;
     const char* ximg = reinterpret_cast<const char*>(X + (long)img * p.H * WIMG * Cin);
     const PfSink pfs = prefetch_issue(p, blockIdx.x, gridDim.x, wave, 8, lane);   // gp_gemm_desc.prefetch (hint)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < XJ; ++j) {
         const int i = wave + 8 * j, px = i * 16 + lrow;
         const int wy = px / WW, wx = px - wy * WW;
         const int gy = h0 - 1 + wy, gx = wx - 1;
@@ -982,7 +989,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         const char* base = reinterpret_cast<const char*>(W) + plane + (tap * Cin + cc * 32) * 2;
         const unsigned d = lds0 + buf * WST + wave * 1024;
         glds16_s(base, woff[0], d);
-        glds16_s(base, woff[1], d + 8192);
+        if constexpr (WPI == 2) glds16_s(base, woff[WPI - 1], d + 8192);
     };
     auto stage_x = [&](int j, int g) {        // one 16-pixel piece of the window of chunk g
         int cc = g;
@@ -998,7 +1005,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
         f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!SPL && p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + a * 16 + fq * 4);   // (SPL: the generic epilogue adds it)
+        if (!SPL && p.bias) init = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + a * 16 + fq * 4);   // (SPL: the generic epilogue adds it)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = init;
     }
@@ -1025,17 +1032,17 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 
     // ---- prologue: window of chunk 0, W of steps 0 and 1
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < XJ; ++j)
         if (wave + 8 * j < NI) stage_x(j, 0);
 #pragma unroll
     for (int i = 0; i < LEAD; ++i) stage_w(i, 0, i);
-    wait_vmcnt(2 * (LEAD - 1));
+    wait_vmcnt(WPI * (LEAD - 1));
     prefetch_retire(pfs);
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();
 
     uint4 xf[MT], wf[NT];
-    int st = 0, rbuf = 0, wbuf = LEAD, ops1 = 2, ops2 = 2;   // DMA ops issued one / two phases ago (W of steps 1..LEAD-1 at first)
+    int st = 0, rbuf = 0, wbuf = LEAD, ops1 = WPI, ops2 = WPI;   // DMA ops issued one / two phases ago (W of steps 1..LEAD-1 at first)
     for (int cc = 0; cc < NG; ++cc) {      // (cc = global chunk index; SPL: segment cc / NCC)
         if constexpr (SPL) {
             if (cc == 2 * NCC) {            // the cross terms are complete: scale them once, exactly, then add x_hi w_hi
@@ -1057,10 +1064,10 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             for (int mt = 0; mt < MT; ++mt)
                 xf[mt] = *reinterpret_cast<const uint4*>(smem + (xa[mt] + xdk) + kh * WW * 64);
             __builtin_amdgcn_sched_barrier(0);
-            // DMA: one window piece of the NEXT chunk during taps 1..4 (its buffer was last read in chunk cc - 1, whose
+            // DMA: one window piece of the NEXT chunk during taps 1..XJ (its buffer was last read in chunk cc - 1, whose
             // reads are two barriers back by tap 1), then the W rows of step st + 2; then wait for the own W of st + 1
             bool xi = false;
-            if (tap >= 1 && tap <= 4) {
+            if (tap >= 1 && tap <= XJ) {
                 xi = cc + 1 < NG && wave + 8 * (tap - 1) < NI && p.dbg != 1;
                 if (xi) stage_x(tap - 1, cc + 1);
             }
@@ -1087,7 +1094,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
             }
             // the own W rows of step st + 1 have landed once at most the ops issued after them are outstanding: those of
             // this phase and (LEAD = 3) of the previous one (vmcnt retires in issue order, the window pieces included)
-            const int ops0 = (wi ? 2 : 0) + (xi ? 1 : 0);
+            const int ops0 = (wi ? WPI : 0) + (xi ? 1 : 0);
             wait_vmcnt(LEAD == 3 ? ops0 + ops1 : ops0);
             ops2 = ops1; ops1 = ops0;
             rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
@@ -1111,7 +1118,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     }
     if (!grp) __builtin_amdgcn_s_barrier();
 
-    const int mb = m0 + wm * 128, nb = wn * 64;
+    const int mb = m0 + wm * 128, nb = n0 + wn * 64;
     if constexpr (SPL) {
         epilogue_split<MT, NT>(p, acc, smem + wave * 8192, mb, nb, lane);
     } else {
@@ -1567,6 +1574,11 @@ static bool pp_enabled() {
     return on;
 }
 
+static bool conv_wide_enabled() {   // A/B switch: GP_CONV_WIDE=0 keeps the 3x3 window conv on 256 x 256 tiles
+    static const bool on = [] { const char* e = getenv("GP_CONV_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool conv_window_enabled() {   // A/B switch: GP_CONV_WINDOW=0 keeps 3x3 convs on the tap-by-tap ping-pong kernel
     static const bool on = [] { const char* e = getenv("GP_CONV_WINDOW"); return !(e && e[0] == '0'); }();
     return on;
@@ -1788,6 +1800,9 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(win_ok, "gp_gemm: variant 13 needs a 3x3 s1 p1 fp16 conv with Cout 256, W in {64, 32, 16}");
         p.tiles_m = d->M / 256;
         p.tiles_n = 1;
+        // wide tile (512 pixels x 128 channels) where it fits: bitwise the 256 x 256 tile's results, 2.3-3.5 % faster (scripts/conv_wide_ab.py,
+        // profiles/r04_conv_wide_tile_ab.txt); dbg code 8 (variant 813) forces it, 9 (variant 913) / GP_CONV_WIDE=0 keep the square tile
+        const bool wide = !split && d->Win >= 32 && d->M % 512 == 0 && d->H % (512 / d->Win) == 0 && p.dbg != 9 && (p.dbg == 8 || conv_wide_enabled());
         // 4-stage W ring, DMA lead 2 (a 5-stage / lead-3 instantiation spilled 43 registers and ran 1.6x slower)
         if (split) {
             if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
@@ -1798,6 +1813,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         else if (d->Win == 64 && p.dbg == 7) hipLaunchKernelGGL((conv3_pp_kernel<64, 4, false, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else if (d->Win == 32 && p.dbg == 7) hipLaunchKernelGGL((conv3_pp_kernel<32, 4, false, true>), dim3(p.tiles_m), dim3(512), 0, s, p);
 #endif
+        else if (wide && d->Win == 64) { p.tiles_m = d->M / 512; hipLaunchKernelGGL((conv3_pp_kernel<64, 4, false, false, true>), dim3(p.tiles_m * 2), dim3(512), 0, s, p); }
+        else if (wide && d->Win == 32) { p.tiles_m = d->M / 512; hipLaunchKernelGGL((conv3_pp_kernel<32, 4, false, false, true>), dim3(p.tiles_m * 2), dim3(512), 0, s, p); }
         else if (d->Win == 64) hipLaunchKernelGGL((conv3_pp_kernel<64, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else if (d->Win == 32) hipLaunchKernelGGL((conv3_pp_kernel<32, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3_pp_kernel<16, 4>), dim3(p.tiles_m), dim3(512), 0, s, p);

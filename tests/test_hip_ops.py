@@ -155,6 +155,28 @@ def test_gemm_pingpong_bitwise_vs_plain_schedule(variant):
         assert torch.equal(o.conv2d_nhwc(xc, wc, 3, 3, 1, 1, variant=variant), ref)
 
 
+def test_conv_window_wide_tile_bitwise_vs_square_tile():
+    """The 3x3 LDS-window conv on 512-pixel x 128-channel tiles (variant 813; the default where it fits since round 4) against
+    256 x 256 tiles (913): same K order per accumulator, so output and fused GroupNorm statistics must be bit-identical, over
+    repeated launches -- at one tile per image half (W = 32: 16 rows), at 8 rows of a 64-wide image, with bias + GELU and without;
+    shapes the wide tile does not fit (W = 16; an odd number of 256-pixel tiles) fall back to the square tile."""
+    o = ops()
+    dt = torch.float16
+    for (B, R, epi, bias) in [(2, 64, o.EPI_NONE, False), (3, 32, o.EPI_GELU, True), (5, 64, o.EPI_GELU, True), (4, 32, o.EPI_RELU, False)]:
+        x = rnd(B, R, R, 256, seed=141).to("cuda", dt)
+        w = rnd(256, 9 * 256, seed=142, scale=0.02).to("cuda", dt)
+        b = rnd(256, seed=143).cuda() if bias else None
+        g_ref, g_out = torch.zeros(B * (R * R // 64) * 64, device="cuda"), torch.ones(B * (R * R // 64) * 64, device="cuda")
+        ref = o.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=b, epilogue=epi, variant=913, gn=(g_ref, 32, R * R))
+        for _ in range(3):
+            out = o.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=b, epilogue=epi, variant=813, gn=(g_out, 32, R * R))
+            assert torch.equal(out, ref) and torch.equal(g_out, g_ref), (B, R, epi)
+        assert torch.equal(o.conv2d_nhwc(x, w, 3, 3, 1, 1, bias=b, epilogue=epi, variant=13), ref)       # the automatic choice between the two
+    x16 = rnd(6, 16, 16, 256, seed=144).to("cuda", dt)      # W = 16: square tile only
+    w = rnd(256, 9 * 256, seed=142, scale=0.02).to("cuda", dt)
+    assert torch.equal(o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=813), o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=913))
+
+
 @pytest.mark.parametrize("variant", [16, 17])
 def test_gemm_weights_in_registers_variant(variant):
     """Variants 16 / 17 (K = 512, a 256-row slice of W resident in registers, X streamed in 32-row tiles, GELU in the MFMA
