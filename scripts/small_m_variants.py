@@ -41,7 +41,7 @@ for name, M, N, K, epi in gemms:
     gamma, b = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
     kw = dict(gamma=gamma, residual=res) if epi == ops.EPI_SCALE_RES else {}
     r = {}
-    for v, sk in ((0, None), (7, 1), (4, 1), (5, 1), (9, 1), (8, 1), (2, 1), (4, 2), (4, 4), (4, 8), (4, 16)):
+    for v, sk in ((0, None), (7, 1), (4, 1), (5, 1), (9, 1), (8, 1), (2, 1), (16, 1), (17, 1), (4, 2), (4, 4), (4, 8), (4, 16)):
         try:
             r[f"v{v}" + (f" splitK{sk}" if sk and sk > 1 else "") if v else "auto"] = round(graph_time(lambda: ops.gemm(x, w, out, bias=b, epilogue=epi, variant=v, splitk=sk, **kw)), 1)
         except Exception as e:
