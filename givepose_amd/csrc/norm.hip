@@ -5,6 +5,15 @@
 // is one contiguous run per CT lanes; 256-thread blocks hold PG = 256 / CT pixel groups.
 #include "common.hpp"
 
+#ifdef GP_DW_STAMPS   // investigation build: s_memtime stamps of ONE workgroup of dwconv7_ln_mfma_kernel (scripts/dw_stamps.py)
+__device__ unsigned long long gp_dw_stamp_buf[8 * 16];
+extern "C" int gp_dw_stamps_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(gp_dw_stamp_buf), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : 1;
+}
+#define GP_DW_MARK(k) do { if (blockIdx.x == gridDim.x / 2 + 1 && blockIdx.y == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) gp_dw_stamp_buf[(threadIdx.x >> 6) * 16 + (k)] = t__; } } while (0)
+#else
+#define GP_DW_MARK(k) do { } while (0)
+#endif
 namespace {
 
 // Sum NV values over the CT threads (CT power of two, 16..256, aligned) that share this thread's
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    GP_DW_MARK(0);
     const int tpr = W / TW, tpi = tpr * (H / TH);
     const int bid = xcd_chunk(blockIdx.x, gridDim.x);   // tiles of an XCD = a contiguous run of rows (common.hpp)
     const int b = bid / tpi, tin = bid - b * tpi;
@@ -405,6 +415,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         }
     }
     if (dbg != 6 && dbg != 8) issue(0, 0);
+    GP_DW_MARK(1);
 
     // lane roles.  B / D column: output pixel n of the row; q = lane >> 4: as a B lane the input row of the K block, as a D lane
     // the rows 4q .. 4q + 3 of D = output row 2p + (q >> 1), channels 8 o + 4 (q & 1) .. + 4 of the wave's octet o.  As an A
@@ -439,8 +450,11 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
 
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
+        if (s == 0) GP_DW_MARK(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s == 0) GP_DW_MARK(3);
         __syncthreads();
+        if (s == 0) GP_DW_MARK(4);
         if (NBUF == 2 && s + 1 < NSLAB && dbg != 6 && dbg != 8) issue(s + 1, (s + 1) & 1);
         const char* in_s = dsm + (s & (NBUF - 1)) * BUF;
         const char* w_s = in_s + IN_INSTR * 1024;
@@ -495,6 +509,7 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         }
     }
 
+    GP_DW_MARK(5);
     // D layout: lane (n, q) holds, of slab s, row pair pp and octet o, the channels s 128 + wave 16 + 8 o + 4 (q & 1) + {0..3} of
     // pixel (row 2 pp + (q >> 1), n).  Bias, then LayerNorm over C.
     const int rsel = q >> 1;
@@ -576,7 +591,9 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         a2 += __shfl_xor(a2, 16);
         if ((q & 1) == 0) { red_s[wave * 64 + (2 * pp + rsel) * 16 + n] = a; red2_s[wave * 64 + (2 * pp + rsel) * 16 + n] = a2; }
     }
+    GP_DW_MARK(6);
     __syncthreads();
+    GP_DW_MARK(7);
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
         float a = 0.f, a2 = 0.f;
@@ -606,7 +623,9 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
                 *reinterpret_cast<half4*>(out_s + px * (C * 2) + ((chunk ^ n) << 4) + (q & 1) * 8) = ov;
             }
         }
+    GP_DW_MARK(8);
     __syncthreads();
+    GP_DW_MARK(9);
     const int cpp = C / 8;   // 16-byte chunks per pixel
     for (int i = tid; i < 64 * cpp; i += 512) {
         const int px = i / cpp, c = i - px * cpp;
@@ -615,6 +634,11 @@ __global__ __launch_bounds__(512, NBUF == 1 ? 2 : 1) void dwconv7_ln_mfma_kernel
         if (dbg != 9 || v.x == 0x12345678u)
             *reinterpret_cast<uint4*>(y + (((long)b * H + h0 + t) * W + w0 + mm) * C + c * 8) = v;
     }
+    GP_DW_MARK(10);
+#ifdef GP_DW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_DW_MARK(11);
+#endif
 }
 
 template <int NSLAB, int NBUF>
