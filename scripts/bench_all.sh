@@ -1,6 +1,6 @@
 #!/bin/bash
-# one bench line per BASELINE.json config that fits one GPU (profiles/r03_bench_<name>.json);
-# the headline config is the default command itself: python3 bench.py > profiles/r03_bench_full.json
+# one bench line per BASELINE.json config that fits one GPU (profiles/r04_bench_<name>.json);
+# the headline config is the default command itself: python3 bench.py > profiles/r04_bench_full.json
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 hostname > gpurun_out/bench_all_host.txt; /opt/rocm/bin/rocm-smi --showserial 2>/dev/null | grep -i serial >> gpurun_out/bench_all_host.txt
