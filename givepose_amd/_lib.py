@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
-ABI_VERSION = 310        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
+ABI_VERSION = 311        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
 GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
@@ -54,6 +54,7 @@ PROTOTYPES = {
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),
     "gp_groupnorm_stats": ([_P] * 2 + [c_int] * 5 + [_P], c_int),
     "gp_groupnorm_apply": ([_P] * 5 + [c_int] * 4 + [c_float] + [c_int] * 4 + [_P], c_int),
+    "gp_groupnorm_upsample2x": ([_P] * 5 + [c_int] * 5 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_groupnorm_apply_xyz": ([_P] * 8 + [c_int] * 4 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_upsample_bilinear2x": ([_P, _P] + [c_int] * 5 + [_P], c_int),
     "gp_deconv_col2im": ([_P, _P] + [c_int] * 5 + [_P], c_int),

@@ -188,6 +188,37 @@ __device__ __forceinline__ void gelu_poly2_slice(f32x2& x, f32x2& xc, f32x2& t, 
         else if constexpr (S == 11) x[e] = vmul(x[e], p[e]);
     }
 }
+// Bilinear x2 blend with pinned roundings (gp_upsample_bilinear2x and gp_groupnorm_upsample2x must agree bit for bit, whatever the
+// compiler would contract): h = fma(hx, a, lx * b) along the row, then out = fma(hy, h0, ly * h1) across the two rows.
+// src = dst * (in - 1) / (out - 1), rounded once; the empty asm keeps the product from being contracted into the `src - floor`
+// that follows (which one kernel might get and the other not).
+__device__ __forceinline__ float bilerp_src(float ratio, int dst) {
+    float s = ratio * (float)dst;
+    asm volatile("" : "+v"(s));
+    return s;
+}
+__device__ __forceinline__ float bilerp_h(float hx, float a, float lx, float b) { return __fmaf_rn(hx, a, __fmul_rn(lx, b)); }
+__device__ __forceinline__ float bilerp_v(float hy, float h0, float ly, float h1) { return __fmaf_rn(hy, h0, __fmul_rn(ly, h1)); }
+// The vertical step of a whole 16-byte vector.  fp16 storage: the fma and the conversion are ONE instruction (v_fma_mix{lo,hi}_f16:
+// fp32 fma, result rounded once to fp16), written out here because hipcc forms it in some instantiations and not in others -- which
+// differ in the last bit on near-ties (round 4: the two upsample kernels disagreed in 1 value of 7000 before this).
+template <typename T>
+__device__ __forceinline__ void bilerp_v_vec(Vec16<T>& o, float hy, const float* h0, float ly, const float* h1) {
+    if constexpr (sizeof(T) == 2) {
+        unsigned int d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float ta = ly * h1[2 * k], tb = ly * h1[2 * k + 1];
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3" : "=v"(d[k]) : "v"(hy), "v"(h0[2 * k]), "v"(ta));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3" : "+v"(d[k]) : "v"(hy), "v"(h0[2 * k + 1]), "v"(tb));
+        }
+        o.u = uint4{d[0], d[1], d[2], d[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) o.set(e, bilerp_v(hy, h0[e], ly, h1[e]));
+    }
+}
+
 __device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }
 
 template <typename T> __device__ __forceinline__ float gelu_for(float v) {

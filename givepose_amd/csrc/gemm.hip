@@ -1566,6 +1566,129 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
     hipLaunchKernelGGL((gemm_big_kernel<T, WM, WN, MT, NT, NS, DB, RB, PP, SPL, R32>), dim3(p.tiles_m * p.tiles_n, splits), dim3(WM * WN * 64), 0, s, p);
 }
 
+
+// ============================================================================ small-M GEMM (variant 18, round 4)
+// The reference's real caller feeds PoseNet the detections of ONE frame (evaluation/evaluate.py:89-117): B = 1..8 crops, i.e.
+// M = 256 B rows at stage 2 of the trunk (27 blocks) and 64 B at stage 3.  The tile kernels above are built for throughput: at M = 256
+// a 128 x 128 tile leaves 32 workgroups on 256 CUs, each walking K through a global -> LDS -> register pipeline whose fill and
+// drain ARE the kernel (10 / 15 us per fc1 / fc2 inside a hipGraph chain; split-K adds a reduce launch).  This kernel is built for
+// latency instead:
+//   * workgroup tile (16 MT) x (16 NT) -- 16 x 32 at M <= 512: 1024 workgroups for fc1, 256 for fc2;
+//   * the four waves of a workgroup split K four ways; a wave loads its operand fragments STRAIGHT from global memory in the MFMA
+//     layout (lane (r, q): row r, 8 consecutive k at 8 q of each 32-wide step = one 16-byte load, X and W alike -- both are
+//     K-contiguous), ALL of its K range at once (one wave per SIMD: up to 16 steps x 3 fragments x 4 = 192 registers in flight),
+//     so a wave pays ONE memory round trip, not one per pipeline stage;
+//   * the four partial tiles meet in LDS and are added in FIXED order (wave 0..3: deterministic, replay-bitwise), then bias /
+//     activation / gamma-residual exactly as the tile kernels' lean epilogue (epi_apply) and one 8-byte store per lane;
+//   * the epilogue's bias / gamma / residual loads are issued before the K loop (their latency hides under the operand loads).
+// Operand roles as everywhere in this file: W is the MFMA A operand and X the B operand, so a lane ends up with 4 consecutive
+// n of one row m.  3 x 3 / stride 1 / pad 1 convs (the heads' 256 -> 256 convs at 16 x 16 .. 64 x 64) run through the same kernel:
+// a row is an output pixel, a 32-wide K step lies inside one filter tap (Cin % 32 == 0), out-of-image taps load nothing.
+template <int MT, int NT, int KCH, bool CONV>
+__global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
+    __shared__ f32x4 red[4][MT * NT][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+    const int nk = p.K >> 5;
+    const int per = (nk + 3) >> 2, k_lo = wave * per, k_hi = min(nk, k_lo + per);
+    const PfSink pf = prefetch_issue(p, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, wave, 4, lane);
+    // ---- epilogue operands of the (tile, lane) this thread finishes (threads 0 .. 64 MT NT - 1)
+    const int et = threadIdx.x >> 6 < MT * NT ? threadIdx.x >> 6 : 0;
+    const int em = m0 + (et / NT) * 16 + r, en = n0 + (et % NT) * 16 + q * 4;
+    f32x4 eb = f32x4{0.f, 0.f, 0.f, 0.f}, eg = eb;
+    half4 er = half4{0, 0, 0, 0};
+    if (threadIdx.x < 64 * MT * NT) {
+        if (p.bias) eb = *reinterpret_cast<const f32x4*>(p.bias + en);
+        if (p.epi == GP_EPI_SCALE_RES) eg = *reinterpret_cast<const f32x4*>(p.gamma + en);
+        if (p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) er = load_res4<half_t>(p, em, en);
+    }
+    // ---- operand rows
+    const half_t* wrow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = reinterpret_cast<const half_t*>(p.W) + (long)(n0 + nt * 16 + r) * p.K + q * 8;
+    const half_t* xrow[MT];
+    int py[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + mt * 16 + r;
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo, b = m / hw, rem = m - b * hw;
+            py[mt] = rem / p.Wo;
+            px[mt] = rem - py[mt] * p.Wo;
+            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + ((long)b * p.H * p.Win) * p.Cin + q * 8;
+        } else {
+            py[mt] = px[mt] = 0;
+            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + (long)m * p.ldx + q * 8;
+        }
+    }
+    const int cpt = CONV ? p.Cin >> 5 : 1;      // K steps per filter tap
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = k_lo; kb < k_hi; kb += KCH) {
+        half8 wf[KCH][NT], xf[KCH][MT];
+#pragma unroll
+        for (int s = 0; s < KCH; ++s) {
+            const int ks = min(kb + s, k_hi - 1);         // steps past the range reload the last one (never used)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[s][nt] = *reinterpret_cast<const half8*>(wrow[nt] + (long)ks * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (CONV) {
+                    const int tap = ks / cpt, c0 = (ks - tap * cpt) * 32;
+                    const int dy = tap / p.KW, dx = tap - dy * p.KW;
+                    const int iy = py[mt] * p.stride - p.pad + dy, ix = px[mt] * p.stride - p.pad + dx;
+                    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.Win;
+                    const half_t* src = xrow[mt] + ((long)(in ? iy : 0) * p.Win + (in ? ix : 0)) * p.Cin + c0;
+                    const half8 v = *reinterpret_cast<const half8*>(src);
+                    xf[s][mt] = in ? v : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                } else {
+                    xf[s][mt] = *reinterpret_cast<const half8*>(xrow[mt] + (long)ks * 32);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KCH; ++s) {
+            if (kb + s < k_hi) {                          // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][nt], xf[s][mt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    prefetch_retire(pf);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) red[wave][mt * NT + nt][lane] = acc[mt][nt];
+    __syncthreads();
+    if (threadIdx.x < 64 * MT * NT) {
+        f32x4 v = red[0][et][lane];
+        v += red[1][et][lane];
+        v += red[2][et][lane];
+        v += red[3][et][lane];
+        v = epi_apply<half_t>(p.epi, v, eb, eg, er);
+        store4<half_t>(p, em, en, v);
+    }
+}
+
+template <int MT, int NT, bool CONV>
+static void launch_smallm(const GemmKP& p, hipStream_t s) {
+    const int per = (p.K / 32 + 3) / 4, rounds = (per + 15) / 16, kch = (per + rounds - 1) / rounds;
+    const dim3 grid(p.N / (16 * NT), p.M / (16 * MT));
+#define GP_SM(KCH) hipLaunchKernelGGL((gemm_smallm_kernel<MT, NT, KCH, CONV>), grid, dim3(256), 0, s, p)
+    if (kch <= 2) GP_SM(2);
+    else if (kch <= 4) GP_SM(4);
+    else if (kch <= 8) GP_SM(8);
+    else if (kch == 9) GP_SM(9);
+    else GP_SM(16);
+#undef GP_SM
+}
+
 }  // namespace
 
 // A/B switch for bench runs on one device: GP_GEMM_PP=0 keeps the ping-pong kernel out of the automatic choice
@@ -1611,6 +1734,15 @@ static bool wreg_enabled() {
 
 static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the ping-pong kernel when batches overlap (GP_GEMM_CO_MIN_TILES: A/B)
     static const long k = [] { const char* e = getenv("GP_GEMM_CO_MIN_TILES"); return e ? atol(e) : 32l; }();
+    return k;
+}
+
+static long smallm_max() {   // largest M of the latency kernel (variant 18); GP_GEMM_SMALLM_MAX: A/B switch, 0 = never
+    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_MAX"); return e ? atol(e) : 1024l; }();
+    return k;
+}
+static long smallm_one_tile_max() {   // up to here 16-row workgroup tiles, above 32-row tiles (GP_GEMM_SMALLM_ONE: A/B switch)
+    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_ONE"); return e ? atol(e) : 512l; }();
     return k;
 }
 
@@ -1709,9 +1841,19 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          p.splitk == 1 && !d->gn_partial && d->epilogue <= GP_EPI_LRELU && d->ldc % 4 == 0 &&
                          ((size_t)d->C & 7) == 0 && ((size_t)d->X & 15) == 0 && ((size_t)d->W & 15) == 0 &&
                          (!d->bias || ((size_t)d->bias & 15) == 0);
+    // few rows (the detections of one frame): the latency kernel (variant 18), whatever split-K factor the caller worked out for the
+    // tile kernels.  GP_GEMM_SMALLM_MAX: largest M that goes there (A/B switch; 0 = never)
+    const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && !d->gn_partial && d->epilogue != GP_EPI_LNFOLD_GELU &&
+                           d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
+                           ((size_t)d->W & 15) == 0 && ((size_t)d->C & 7) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
+                           (!d->gamma || ((size_t)d->gamma & 15) == 0) && (!d->residual || ((size_t)d->residual & 7) == 0);
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
+    if ((variant == 0 && smallm_ok && d->M <= smallm_max()) || variant == 18) {
+        variant = 18;
+        p.splitk = 1;
+    }
     if (variant == 0) {
         // measured per shape (scripts/gemm_bench.py): where 256x256 tiles fill the chip (N % 256 == 0, >= 192 tiles)
         // the ping-pong kernel (10) for K >= 512 and the 256x128 tile at two workgroups per CU (8) for shorter K
@@ -1744,7 +1886,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (!d->out_f32 || split) && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 && !d->out_planes &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
-    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || variant == 16 || variant == 17) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
+    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || (variant >= 16 && variant <= 18)) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
     // c16 is written by the generic epilogue of gemm_big_kernel only (out_f32 keeps every tile off the lean one); the window conv
@@ -1752,6 +1894,13 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     GP_REQUIRE(!d->c16 || (variant != 13 && variant != 16 && variant != 17 && !split), "gp_gemm: c16 runs on the tile kernels (variants 2-5, 7-12), not on %d%s", variant, split ? " split" : "");
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
+    if (variant == 18) {
+        GP_REQUIRE(smallm_ok, "gp_gemm: variant 18 needs a plain fp16 GEMM / conv (fp16 out, no split-K, no fused GroupNorm), N %% 32 == 0, M %% 16 == 0");
+        const bool two = d->M % 32 == 0 && d->M > smallm_one_tile_max();      // 32-row tiles once 16-row tiles alone fill the chip
+        if (d->KH > 0) { if (two) launch_smallm<2, 2, true>(p, s); else launch_smallm<1, 2, true>(p, s); }
+        else { if (two) launch_smallm<2, 2, false>(p, s); else launch_smallm<1, 2, false>(p, s); }
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     if (variant == 16) {
         GP_REQUIRE(wreg_ok, "gp_gemm: variant 16 needs a plain fp16 GEMM with K = 512, N %% 256 == 0, M %% 32 == 0, epilogue none/gelu/relu/lrelu");
         const int nsl = d->N / 256, tiles = d->M / 32;

@@ -71,13 +71,15 @@ template <> __device__ __forceinline__ void mac16<half_t>(float* acc, const Vec1
 }
 
 // ---------------------------------------------------------------------------- dwconv + LN (+act)
-template <typename T, int KS>
+// PPT pixels (one strip of a row) per thread: 8 for throughput; 2 where 8 would leave most of the chip idle (the detections of
+// one frame: 256 pixels of a stage-2 map are 8 workgroups at PPT = 8 and 32 at PPT = 2 -- more halo reads, all of them cache hits)
+template <typename T, int KS, int PPT>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const T* __restrict__ wt,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, T* __restrict__ y, int H,
                                                         int W, int C, float eps, int act, long n_pixels, long pl) {
-    constexpr int VEC = Vec16<T>::N, PPT = 8, R = KS / 2;
+    constexpr int VEC = Vec16<T>::N, R = KS / 2;
     __shared__ float red[4 * PPT];
     const int CT = C / VEC, PG = 256 / CT;
     const int cs = threadIdx.x % CT, pg = threadIdx.x / CT;
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int e = 0; e < VEC; ++e) {
         const int g = (cs * VEC + e) / cpg;
         sc[e] = st[g][1] * gw[e];
-        sh[e] = gb[e] - st[g][0] * sc[e];
+        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
     }
     for (int pb = p0 + pl; pb < p1; pb += 4 * PG) {
         Vec16<T> cur[4];
@@ -858,13 +860,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                 for (int e = 0; e < VEC; e += 2) {
-                    const f32x2 g = gelu_poly2(f32x2{cur[u].get(e) * sc[e] + sh[e], cur[u].get(e + 1) * sc[e + 1] + sh[e + 1]});
+                    const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(cur[u].get(e), sc[e], sh[e]), __fmaf_rn(cur[u].get(e + 1), sc[e + 1], sh[e + 1])});
                     o.set(e, g[0]);
                     o.set(e + 1, g[1]);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(cur[u].get(e) * sc[e] + sh[e], act));
+                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(__fmaf_rn(cur[u].get(e), sc[e], sh[e]), act));
             }
             store16p<T>(y, yo + (long)p * ldy, o, plane);
         }
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
     for (int e = 0; e < VEC; ++e) {
         const int g = (cs * VEC + e) / cpg;
         sc[e] = st[g][1] * gw[e];
-        sh[e] = gb[e] - st[g][0] * sc[e];
+        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
     }
     for (int it0 = 0; it0 < iters; it0 += 4) {
         Vec16<T> vq[4];
@@ -931,13 +933,13 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
                 if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                     for (int e = 0; e < VEC; e += 2) {
-                        const f32x2 g = gelu_poly2(f32x2{v.get(e) * sc[e] + sh[e], v.get(e + 1) * sc[e + 1] + sh[e + 1]});
+                        const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(v.get(e), sc[e], sh[e]), __fmaf_rn(v.get(e + 1), sc[e + 1], sh[e + 1])});
                         a[e] = g[0];
                         a[e + 1] = g[1];
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) a[e] = apply_act(v.get(e) * sc[e] + sh[e], act);
+                    for (int e = 0; e < VEC; ++e) a[e] = apply_act(__fmaf_rn(v.get(e), sc[e], sh[e]), act);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -1061,8 +1063,138 @@ bool ct_ok(int C, int esz) {
     return ct >= 1 && ct <= 256 && (ct & (ct - 1)) == 0;
 }
 
+
+// ---------------------------------------------------------------------------- GroupNorm apply + GELU + bilinear x2 in one pass (round 4)
+// TopDownXyzHead runs conv -> GN -> GELU -> Upsample(x2, bilinear, align_corners) -> conv twice (xyz_head.py:250-264); until round 4
+// that was a GroupNorm-apply pass (read + write of the low-resolution tensor) and an upsample pass.  Here a workgroup owns a 16 x 8
+// OUTPUT tile of one image: its 10 x 6 source pixels are normalised + activated ONCE into LDS (rounded to fp16 exactly as the
+// apply pass stored them), then the output pixels are blended from LDS with the upsample kernel's own roundings (common.hpp: bilerp_*)
+// -- bitwise the two-pass result (tests/test_hip_ops.py), one launch and one low-resolution round trip less.  (Fusing the GELU into
+// the per-output-pixel upsample kernel instead would run it four times per source value: 230 us of VALU issue at 128 crops.)
+template <int CPT>   // output columns per thread in the blend: 16 / (256 / (C / 8)), at least 1
+__global__ __launch_bounds__(256) void gn_upsample2x_kernel(const half_t* __restrict__ x, const float* __restrict__ partial,
+                                                            const float* __restrict__ w, const float* __restrict__ bb,
+                                                            half_t* __restrict__ y, int H, int W, int C, int G, int act,
+                                                            int chunks, float inv_count, float eps) {
+    // 16 x 8 output tile <- 10 x 6 source pixels (30 KB of LDS at C = 256: 4 workgroups per CU).  16 x 16 tiles (less halo, half
+    // the workgroups per CU) measured the same at 128 crops and lose at B = 1: profiles/r04_gn_upsample_ab.txt.
+    constexpr int TO = 16, TS = TO / 2 + 2, TOY = 8, TSY = TOY / 2 + 2;
+    extern __shared__ __attribute__((aligned(16))) char gus[];
+    __shared__ float st[256][2];
+    const int CT = C >> 3, PG = 256 / CT, cpg = C / G;
+    const int cs = threadIdx.x % CT, pl = threadIdx.x / CT;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int b = blockIdx.z, oy0 = blockIdx.y * TOY, ox0 = blockIdx.x * TO;
+    // align_corners = True: src = dst * (in - 1) / (out - 1); the tile's first source row / column
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    const int sy0 = (int)bilerp_src(ry, oy0), sx0 = (int)bilerp_src(rx, ox0);
+    float gw[8], gb[8];
+    load_f32<half_t>(w + cs * 8, gw);
+    load_f32<half_t>(bb + cs * 8, gb);
+    gn_finalize(partial, b, chunks, G, inv_count, eps, st);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (cs * 8 + e) / cpg;
+        sc[e] = st[g][1] * gw[e];
+        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
+    }
+    const half_t* xb = x + ((long)b * H * W) * C + cs * 8;
+    const int NSRC = TSY * TS;
+    for (int pb = pl; pb < NSRC; pb += 4 * PG) {      // phase 1: source tile -> GN + act -> LDS (fp16); four loads in flight per thread
+        Vec16<half_t> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = min(pb + u * PG, NSRC - 1);
+            const int ty = p / TS, tx = p - ty * TS;
+            const int gy = min(sy0 + ty, H - 1), gx = min(sx0 + tx, W - 1);
+            v[u] = load16<half_t>(xb + ((long)gy * W + gx) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pb + u * PG;
+            if (p >= NSRC) break;
+            Vec16<half_t> o;
+            if (act == GP_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(v[u].get(e), sc[e], sh[e]), __fmaf_rn(v[u].get(e + 1), sc[e + 1], sh[e + 1])});
+                    o.set(e, g[0]);
+                    o.set(e + 1, g[1]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.set(e, apply_act(__fmaf_rn(v[u].get(e), sc[e], sh[e]), act));
+            }
+            *reinterpret_cast<uint4*>(gus + ((long)p * CT + cs) * 16) = o.u;
+        }
+    }
+    __syncthreads();
+    // phase 2: the blend is separable -- h(row) = hx * v[row][x0] + lx * v[row][x1], out = hy * h(y0) + ly * h(y1), with exactly the
+    // upsample kernel's roundings (misc.hip: bilerp) -- and a source row's h serves every output row that touches it, so it is
+    // computed once and rolled (12 -> 5 VALU operations per output value).  A thread owns CPT adjacent output columns of one
+    // 8-channel slice and walks the tile's output rows in order; all row decisions are wave-uniform.
+    if (pl * CPT >= TO) return;                       // C < 128: more pixel groups than columns (after the last barrier)
+    float h0[CPT][8], h1[CPT][8], lxs[CPT];
+    int xo[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int ox = min(ox0 + pl * CPT + j, Wo - 1);
+        const float sx = bilerp_src(rx, ox);
+        const int x0 = (int)sx;
+        lxs[j] = sx - x0;
+        xo[j] = ((x0 - sx0) * CT + cs) * 16;
+    }
+    auto hrow = [&](int row, float (&h)[CPT][8]) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            Vec16<half_t> va, vb;
+            va.u = *reinterpret_cast<const uint4*>(gus + (long)row * TS * CT * 16 + xo[j]);
+            vb.u = *reinterpret_cast<const uint4*>(gus + (long)row * TS * CT * 16 + xo[j] + CT * 16);
+            const float lx = lxs[j], hx = 1.f - lx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[j][e] = bilerp_h(hx, va.get(e), lx, vb.get(e));
+        }
+    };
+    int have = -2;
+    const int oyend = min(oy0 + TOY, Ho);
+    for (int oy = oy0; oy < oyend; ++oy) {
+        const float sy = bilerp_src(ry, oy);
+        const int y0 = (int)sy, r = y0 - sy0;
+        const float ly = sy - y0, hy = 1.f - ly;
+        if (r != have) {                              // uniform
+            if (r == have + 1) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h0[j][e] = h1[j][e];
+            } else {
+                hrow(r, h0);
+            }
+            hrow(r + 1, h1);                          // LDS row r + 1 holds source row min(y0 + 1, H - 1)
+            have = r;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int ox = ox0 + pl * CPT + j;
+            if (ox >= Wo) break;
+            Vec16<half_t> o;
+            bilerp_v_vec<half_t>(o, hy, h0[j], ly, h1[j]);
+            store16<half_t>(y + (((long)b * Ho + oy) * Wo + ox) * C + cs * 8, o);
+        }
+    }
+}
+
 }  // namespace
 
+static long dw_narrow_below() {   // strip kernel: 2 pixels per thread when 8 would give fewer workgroups than this (GP_DW_NARROW_BELOW: A/B)
+    static const long k = [] { const char* e = getenv("GP_DW_NARROW_BELOW"); return e ? atol(e) : 128l; }();
+    return k;
+}
+static long dw_mfma_min_wgs() {   // fewest workgroups (4 x 16-pixel tiles) that still go to the MFMA kernel (GP_DW_MFMA_MIN: A/B)
+    static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : 0l; }();
+    return k;
+}
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
     return on;
@@ -1090,7 +1222,7 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && H % 4 == 0 && W % 16 == 0 &&
-        (C == 128 || C == 256 || C == 512)) {
+        (C == 128 || C == 256 || C == 512) && (long)B * (H / 4) * (W / 16) >= dw_mfma_min_wgs()) {
         if (C == 128) launch_dw7_mfma<1, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if (C == 256) launch_dw7_mfma<2, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if ((long)B * (H / 4) * (W / 16) >= 512 || dw_single_buffer()) launch_dw7_mfma<4, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
@@ -1117,10 +1249,15 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
         }
         if (done) GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
-    dim3 grid(cdiv(strips, PG));
-#define GP_DW(T, K) hipLaunchKernelGGL((dwconv_ln_kernel<T, K>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, pl)
-    if (dtype == GP_F16) { if (KS == 7) GP_DW(half_t, 7); else GP_DW(half_t, 3); }
-    else { if (KS == 7) GP_DW(float, 7); else GP_DW(float, 3); }
+    // few pixels (fewer than one 8-pixel-strip workgroup per two CUs): 2 pixels per thread, four times the workgroups
+    const bool narrow = dtype == GP_F16 && cdiv(strips, PG) < dw_narrow_below();
+    dim3 grid(narrow ? cdiv((n_pixels + 1) / 2, PG) : cdiv(strips, PG));
+#define GP_DW(T, K, P) hipLaunchKernelGGL((dwconv_ln_kernel<T, K, P>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, pl)
+    if (dtype == GP_F16) {
+        if (narrow) { if (KS == 7) GP_DW(half_t, 7, 2); else GP_DW(half_t, 3, 2); }
+        else { if (KS == 7) GP_DW(half_t, 7, 8); else GP_DW(half_t, 3, 8); }
+    }
+    else { if (KS == 7) GP_DW(float, 7, 8); else GP_DW(float, 3, 8); }
 #undef GP_DW
     GP_LAUNCH_CHECK("gp_dwconv_ln");
 }
@@ -1204,6 +1341,33 @@ extern "C" int gp_groupnorm_apply(const void* x, const float* partial, const flo
     else
         hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, partial, w, b, (float*)y, HW, C, G, act, ldy, chunks, inv_count, eps, pxb, pl);
     GP_LAUNCH_CHECK("gp_groupnorm_apply");
+}
+
+/* GroupNorm apply (statistics from `partial`, as gp_groupnorm_apply) + activation + bilinear x2 upsample (align_corners) in one pass:
+ * x (B, H, W, C) fp16 -> y (B, 2H, 2W, C) fp16; bitwise gp_groupnorm_apply followed by gp_upsample_bilinear2x. */
+extern "C" int gp_groupnorm_upsample2x(const void* x, const float* partial, const float* w, const float* b, void* y, int B, int H,
+                                       int W, int C, int G, float eps, int act, int chunks_in, int dtype, void* stream) {
+    GP_REQUIRE(x && partial && w && b && y && x != y && B > 0 && H > 1 && W > 1, "gp_groupnorm_upsample2x: bad argument");
+    GP_REQUIRE(dtype == GP_F16, "gp_groupnorm_upsample2x: fp16 storage only (the fp32 modes run the two passes)");
+    GP_REQUIRE(ct_ok(C, 2) && C / 8 <= 64 && G > 0 && G <= 256 && C % G == 0, "gp_groupnorm_upsample2x: unsupported C=%d G=%d", C, G);
+    GP_REQUIRE(B <= 65535 && 2 * H / 8 + 1 <= 65535, "gp_groupnorm_upsample2x: grid too large");
+    const int HW = H * W;
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_NORM, 4.0 * B * HW * C + 8.0 * B * HW * 4 * C, (double)B * HW * C * 2 * 5);
+    gp_timing_label("gn_upsample2x C%d %dx%d act%d", C, H, W, act);
+    const int chunks = chunks_in > 0 ? chunks_in : cdiv(HW, gn_pxb(B, HW));
+    const float inv_count = 1.0f / ((float)HW * (C / G));
+    const int toy = 8;
+    const int lds = (toy / 2 + 2) * 10 * C * 2;      // 30 KB at C = 256
+    GP_REQUIRE(lds <= 60 * 1024, "gp_groupnorm_upsample2x: C=%d needs %d B of LDS", C, lds);
+    dim3 grid(cdiv(2 * W, 16), cdiv(2 * H, toy), B);
+    const int cpt = C / 8 >= 64 ? 4 : C / 8 >= 32 ? 2 : 1;
+#define GP_GNUP(CPT) hipLaunchKernelGGL(gn_upsample2x_kernel<CPT>, grid, dim3(256), lds, s, (const half_t*)x, partial, w, b, (half_t*)y, H, W, C, G, act, chunks, inv_count, eps)
+    if (cpt == 4) GP_GNUP(4);
+    else if (cpt == 2) GP_GNUP(2);
+    else GP_GNUP(1);
+#undef GP_GNUP
+    GP_LAUNCH_CHECK("gp_groupnorm_upsample2x");
 }
 
 extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const float* w, const float* b,

@@ -451,6 +451,15 @@ def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=Fal
     return out
 
 
+def groupnorm_upsample2x(x, w, b, out, G, act, partial, eps=1e-5):
+    """GroupNorm apply (statistics already in ``partial`` in 64-row chunks, from the producing conv) + act + bilinear x2
+    (align_corners) in one pass: x (B,H,W,C) fp16 -> out (B,2H,2W,C) fp16; bitwise groupnorm(fused_stats=True) + upsample_bilinear2x."""
+    B, H, W_, C = x.shape
+    check(_L().gp_groupnorm_upsample2x(_ptr(_contig(x, "x")), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, H, W_, C, G, eps, act,
+                                       H * W_ // 64, dtype_code(x.dtype), _stream()), "gp_groupnorm_upsample2x")
+    return out
+
+
 def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5):
     """GroupNorm apply (statistics already in ``partial`` in 64-row chunks) + act + 1x1 out layer, nothing else written."""
     B, HW, C = x.shape

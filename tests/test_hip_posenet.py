@@ -165,14 +165,19 @@ def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
     # stem on VALU or on MFMA) move it between 2.3e-2 and 6.2e-2.  A regression in any fp16 kernel must not hide behind that
     # crop, so the bound that carries the test is on what the network itself computes -- the rot6d logits BEFORE the
     # normalisation, relative to their scale (measured 4e-3 ... 6e-3) -- plus the distribution of |dR| up to its 99th
-    # percentile; the maximum only gets the ceiling the worst conditioning seen explains (6.2e-2).
+    # percentile; the maximum is bounded per crop by that crop's own conditioning (below).
     per_crop = (out["rot"].cpu() - ref["rot"]).abs().reshape(out["rot"].shape[0], -1).max(1).values.sort().values
     r6 = float((rot6d - ref["rot6d"]).abs().max() / ref["rot6d"].abs().max())
     print("fp16 bs64 per-crop |dR|: median %.4f p90 %.4f p99 %.4f max %.4f; rot6d logits rel %.2e" %
           (float(per_crop[32]), float(per_crop[57]), float(per_crop[62]), float(per_crop[-1]), r6))
     assert r6 < 1.5e-2
     assert float(per_crop[32]) < 8e-3 and float(per_crop[57]) < 2e-2 and float(per_crop[62]) < 5e-2
-    assert err["rot"] < 8e-2 and err["size"] < 3e-2
+    # the maximum itself: every crop within what ITS logit error and conditioning explain (tests/rot_cond.py), no fixed ceiling
+    from rot_cond import rot_error_bound
+    per_u = (out["rot"].cpu() - ref["rot"]).abs().reshape(out["rot"].shape[0], -1).max(1).values.double()
+    bound = rot_error_bound(ref["rot6d"], rot6d)
+    assert bool((per_u <= bound).all()), float((per_u / bound).max())
+    assert err["size"] < 3e-2
     assert err["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max()))
 
 
