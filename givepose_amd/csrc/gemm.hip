@@ -310,17 +310,20 @@ __device__ __forceinline__ void epilogue_lean(const GemmKP& p, f32x4 (&acc)[NT][
 typedef __attribute__((address_space(3))) char lds_char_t;
 
 // gp_gemm_desc.prefetch: the launch's workgroups touch [pf, pf + pf_bytes) once, 1 KB per wave instruction (16 B per lane),
-// at most NPF instructions per wave.  The loads have register destinations that nothing reads -- but a load's registers are
-// written when it LANDS, so they must stay reserved until then: prefetch_issue() returns them, prefetch_retire() is
-// placed behind the kernel's first vmcnt wait (vmcnt retires in issue order and these loads are older than everything the
-// kernel counts, so that wait covers them) and "uses" them there, which keeps hipcc from handing them out earlier.
+// at most NPF instructions per wave.  The loads have register destinations that nothing computes with; prefetch_issue() returns
+// them and prefetch_retire() "uses" them behind the kernel's first vmcnt wait (vmcnt retires in issue order and these loads are
+// older than everything the kernel waits for, so the use costs no stall).  They are ORDINARY loads the compiler knows about:
+// until round 4 they were inline asm, invisible to hipcc's wait-count tracking -- which left it free to move the (as it
+// believed, already written) destination registers' value elsewhere and reuse the registers while the load was still in
+// flight.  In the small-M kernel it did: the landing prefetch overwrote the K-loop counter (memory fault on the one launch of the
+// step whose prefetch is long enough for a second load per wave, found by scripts/b1_eager_probe.py).
 constexpr int NPF = 4;
 typedef unsigned pf_u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: no 'v' constraint)
 struct PfSink { pf_u32x4 r0, r1, r2, r3; };
 __device__ __forceinline__ void prefetch_one(const GemmKP& p, long i, long hi, int lane, pf_u32x4& r) {
     const long off = (i << 10) + lane * 16;
     r = pf_u32x4{0u, 0u, 0u, 0u};
-    if (i < hi && off + 16 <= p.pf_bytes) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(p.pf + off) : "memory");
+    if (i < hi && off + 16 <= p.pf_bytes) r = *reinterpret_cast<const pf_u32x4*>(p.pf + off);
 }
 __device__ __forceinline__ PfSink prefetch_issue(const GemmKP& p, int bid, int nwg, int wave, int nwaves, int lane) {
     PfSink s;
@@ -1584,23 +1587,31 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
 // Operand roles as everywhere in this file: W is the MFMA A operand and X the B operand, so a lane ends up with 4 consecutive
 // n of one row m.  3 x 3 / stride 1 / pad 1 convs (the heads' 256 -> 256 convs at 16 x 16 .. 64 x 64) run through the same kernel:
 // a row is an output pixel, a 32-wide K step lies inside one filter tap (Cin % 32 == 0), out-of-image taps load nothing.
-template <int MT, int NT, int KCH, bool CONV>
+template <int MT, int NT, int KCH, bool CONV, bool GN>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
+    static_assert(!GN || (MT == 4 && NT == 2), "fused GroupNorm statistics: one workgroup = one 64-row chunk x 32 columns");
     __shared__ f32x4 red[4][MT * NT][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    __shared__ float gred[4][4][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;     // (wave stays a vector value: the conv's tap state in SGPRs spilled them)
     const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
     const int nk = p.K >> 5;
     const int per = (nk + 3) >> 2, k_lo = wave * per, k_hi = min(nk, k_lo + per);
     const PfSink pf = prefetch_issue(p, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, wave, 4, lane);
-    // ---- epilogue operands of the (tile, lane) this thread finishes (threads 0 .. 64 MT NT - 1)
-    const int et = threadIdx.x >> 6 < MT * NT ? threadIdx.x >> 6 : 0;
-    const int em = m0 + (et / NT) * 16 + r, en = n0 + (et % NT) * 16 + q * 4;
-    f32x4 eb = f32x4{0.f, 0.f, 0.f, 0.f}, eg = eb;
-    half4 er = half4{0, 0, 0, 0};
-    if (threadIdx.x < 64 * MT * NT) {
-        if (p.bias) eb = *reinterpret_cast<const f32x4*>(p.bias + en);
-        if (p.epi == GP_EPI_SCALE_RES) eg = *reinterpret_cast<const f32x4*>(p.gamma + en);
-        if (p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) er = load_res4<half_t>(p, em, en);
+    // ---- epilogue operands of the (tile, lane) pairs this thread finishes: wave w takes tiles w, w + 4, ...
+    constexpr int TPW = (MT * NT + 3) / 4;
+    f32x4 eb[TPW], eg[TPW];
+    half4 er[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int et = wave + 4 * i;
+        eb[i] = eg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        er[i] = half4{0, 0, 0, 0};
+        if (et < MT * NT) {
+            const int em = m0 + (et / NT) * 16 + r, en = n0 + (et % NT) * 16 + q * 4;
+            if (p.bias) eb[i] = *reinterpret_cast<const f32x4*>(p.bias + en);
+            if (p.epi == GP_EPI_SCALE_RES) eg[i] = *reinterpret_cast<const f32x4*>(p.gamma + en);
+            if (p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) er[i] = load_res4<half_t>(p, em, en);
+        }
     }
     // ---- operand rows
     const half_t* wrow[NT];
@@ -1627,6 +1638,14 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // conv: (filter row, filter column, channel step) of the K step at hand, advanced step by step (no division per step)
+    int dy = 0, dx = 0, cc = 0;
+    if constexpr (CONV) {
+        const int tap = k_lo / cpt;
+        cc = k_lo - tap * cpt;
+        dy = tap / p.KW;
+        dx = tap - dy * p.KW;
+    }
     for (int kb = k_lo; kb < k_hi; kb += KCH) {
         half8 wf[KCH][NT], xf[KCH][MT];
 #pragma unroll
@@ -1634,19 +1653,26 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
             const int ks = min(kb + s, k_hi - 1);         // steps past the range reload the last one (never used)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[s][nt] = *reinterpret_cast<const half8*>(wrow[nt] + (long)ks * 32);
+            const int c0 = cc * 32;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (CONV) {
-                    const int tap = ks / cpt, c0 = (ks - tap * cpt) * 32;
-                    const int dy = tap / p.KW, dx = tap - dy * p.KW;
+                    // (steps past the range: some tap past the last one -- in the image or masked, never used)
                     const int iy = py[mt] * p.stride - p.pad + dy, ix = px[mt] * p.stride - p.pad + dx;
-                    const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.Win;
-                    const half_t* src = xrow[mt] + ((long)(in ? iy : 0) * p.Win + (in ? ix : 0)) * p.Cin + c0;
-                    const half8 v = *reinterpret_cast<const half8*>(src);
-                    xf[s][mt] = in ? v : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    // out-of-image taps: the load goes to pixel (0, 0) and is masked with a per-lane word built by integer arithmetic
+                    // (sign bit of iy | H-1-iy | ix | W-1-ix): a compare + select keeps one 64-bit lane mask per fragment in
+                    // SGPRs until the load lands -- 36 of them in the 64-row tile spilled SGPRs
+                    const int keep = ~((iy | (p.H - 1 - iy) | ix | (p.Win - 1 - ix)) >> 31);
+                    const half_t* src = xrow[mt] + ((long)(iy & keep) * p.Win + (ix & keep)) * p.Cin + c0;
+                    pf_u32x4 u = *reinterpret_cast<const pf_u32x4*>(src);
+                    u &= pf_u32x4{(unsigned)keep, (unsigned)keep, (unsigned)keep, (unsigned)keep};
+                    xf[s][mt] = __builtin_bit_cast(half8, u);
                 } else {
                     xf[s][mt] = *reinterpret_cast<const half8*>(xrow[mt] + (long)ks * 32);
                 }
+            }
+            if constexpr (CONV) {
+                if (++cc == cpt) { cc = 0; if (++dx == p.KW) { dx = 0; ++dy; } }
             }
         }
 #pragma unroll
@@ -1660,32 +1686,66 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
             }
         }
     }
-    prefetch_retire(pf);
+    prefetch_retire(pf);                                 // (a wave with an empty K range waits for its prefetch loads here)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[wave][mt * NT + nt][lane] = acc[mt][nt];
     __syncthreads();
-    if (threadIdx.x < 64 * MT * NT) {
-        f32x4 v = red[0][et][lane];
-        v += red[1][et][lane];
-        v += red[2][et][lane];
-        v += red[3][et][lane];
-        v = epi_apply<half_t>(p.epi, v, eb, eg, er);
-        store4<half_t>(p, em, en, v);
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int et = wave + 4 * i;
+        if (et < MT * NT) {
+            f32x4 v = red[0][et][lane];
+            v += red[1][et][lane];
+            v += red[2][et][lane];
+            v += red[3][et][lane];
+            v = epi_apply<half_t>(p.epi, v, eb[i], eg[i], er[i]);
+            if constexpr (GN) {      // as the tile kernels: statistics of the fp32 values, before the fp16 rounding of the store
+                gs += (v[0] + v[1]) + (v[2] + v[3]);
+                gq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+            store4<half_t>(p, m0 + (et / NT) * 16 + r, n0 + (et % NT) * 16 + q * 4, v);
+        }
+    }
+    if constexpr (GN) {
+        // fused GroupNorm statistics: (sum, sum of squares) of this 64-row chunk per channel group, in the tile kernels' layout
+        // (B, HW / 64, G, 2).  Wave w finished m-tiles w / 2 and w / 2 + 2 of n-tile w % 2: 16 rows by shuffle, the group's second
+        // 4-column quad (8 channels per group) by shuffle, the two waves of an n-tile through LDS in fixed order.
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
+        if (p.gn_cpg == 8) { gs += __shfl_xor(gs, 16, 64); gq += __shfl_xor(gq, 16, 64); }
+        if (r == 0) { gred[wave][q][0] = gs; gred[wave][q][1] = gq; }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const int nt = threadIdx.x >> 2, qq = threadIdx.x & 3;
+            if (p.gn_cpg == 4 || (qq & 1) == 0) {
+                const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
+                const int b = m0 / p.gn_hw, ch = (m0 - b * p.gn_hw) >> 6;
+                float* o = p.gn_partial + (((long)b * cpi + ch) * G + (n0 + nt * 16 + qq * 4) / p.gn_cpg) * 2;
+                o[0] = gred[nt][qq][0] + gred[nt + 2][qq][0];
+                o[1] = gred[nt][qq][1] + gred[nt + 2][qq][1];
+            }
+        }
     }
 }
 
-template <int MT, int NT, bool CONV>
+template <int MT, int NT, bool CONV, bool GN>
 static void launch_smallm(const GemmKP& p, hipStream_t s) {
-    const int per = (p.K / 32 + 3) / 4, rounds = (per + 15) / 16, kch = (per + rounds - 1) / rounds;
+    // fragments in flight: (MT + NT) x KCH x 4 registers <= 256 (one wave per SIMD); convs: 9 (3 x 3 x Cin / 128 steps per wave come
+    // in nines, and 16 unrolled steps of scalar tap state spilled SGPRs)
+    constexpr int KMAX = (CONV || MT + NT > 4) ? 9 : 16;
+    const int per = (p.K / 32 + 3) / 4, rounds = (per + KMAX - 1) / KMAX, kch = (per + rounds - 1) / rounds;
     const dim3 grid(p.N / (16 * NT), p.M / (16 * MT));
-#define GP_SM(KCH) hipLaunchKernelGGL((gemm_smallm_kernel<MT, NT, KCH, CONV>), grid, dim3(256), 0, s, p)
-    if (kch <= 2) GP_SM(2);
-    else if (kch <= 4) GP_SM(4);
-    else if (kch <= 8) GP_SM(8);
-    else if (kch == 9) GP_SM(9);
-    else GP_SM(16);
+#define GP_SM(KCH) hipLaunchKernelGGL((gemm_smallm_kernel<MT, NT, (KCH) <= KMAX ? (KCH) : KMAX, CONV, GN>), grid, dim3(256), 0, s, p)
+    if (kch <= 2) { GP_SM(2); return; }
+    if (kch <= 4) { GP_SM(4); return; }
+    if constexpr (!CONV) {          // (the 8-step conv instantiation of the 64-row tile spilled SGPRs: convs go 2 / 4 / 9)
+        if (kch <= 8) { GP_SM(8); return; }
+    }
+    if (kch <= 9) GP_SM(9);
+    else GP_SM(KMAX);
 #undef GP_SM
 }
 
@@ -1737,12 +1797,8 @@ static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the pi
     return k;
 }
 
-static long smallm_max() {   // largest M of the latency kernel (variant 18); GP_GEMM_SMALLM_MAX: A/B switch, 0 = never
-    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_MAX"); return e ? atol(e) : 1024l; }();
-    return k;
-}
-static long smallm_one_tile_max() {   // up to here 16-row workgroup tiles, above 32-row tiles (GP_GEMM_SMALLM_ONE: A/B switch)
-    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_ONE"); return e ? atol(e) : 512l; }();
+static long smallm_max_bytes() {   // most L2 -> CU operand traffic a launch of the latency kernel (variant 18) may have; GP_GEMM_SMALLM_MB: A/B, 0 = never
+    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_MB"); return (e ? atol(e) : 72l) << 20; }();
     return k;
 }
 
@@ -1843,16 +1899,26 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          (!d->bias || ((size_t)d->bias & 15) == 0);
     // few rows (the detections of one frame): the latency kernel (variant 18), whatever split-K factor the caller worked out for the
     // tile kernels.  GP_GEMM_SMALLM_MAX: largest M that goes there (A/B switch; 0 = never)
-    const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && !d->gn_partial && d->epilogue != GP_EPI_LNFOLD_GELU &&
+    const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
+                           (!d->gn_partial || (d->M % 64 == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
                            d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
                            ((size_t)d->W & 15) == 0 && ((size_t)d->C & 7) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
                            (!d->gamma || ((size_t)d->gamma & 15) == 0) && (!d->residual || ((size_t)d->residual & 7) == 0);
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
-    if ((variant == 0 && smallm_ok && d->M <= smallm_max()) || variant == 18) {
+    // workgroup tile of the latency kernel: 16 MT x 32 with the smallest MT in {1, 2, 4} whose operand traffic -- every workgroup
+    // reads its (16 MT + 32) rows of K halfs from L2 -- stays below what the L2 delivers in the time of a launch (measured,
+    // scripts/small_m_variants.py: ~8 us per launch up to ~50 MB, 17-25 us at 130-200 MB).  None: the tile kernels.
+    int sm_mt = 0;
+    if (smallm_ok) {
+        for (int mt = d->gn_partial ? 4 : 1; mt <= 4 && !sm_mt; mt *= 2)     // fused GroupNorm statistics: 64-row workgroup tiles
+            if (d->M % (16 * mt) == 0 && (double)(d->M / (16 * mt)) * (d->N / 32) * (16 * mt + 32) * d->K * 2.0 <= (double)smallm_max_bytes()) sm_mt = mt;
+    }
+    if ((variant == 0 && sm_mt) || variant == 18) {
         variant = 18;
         p.splitk = 1;
+        if (!sm_mt) sm_mt = d->M % 64 == 0 && (d->M >= 2048 || d->gn_partial) ? 4 : d->M % 32 == 0 && d->M > 512 ? 2 : 1;     // explicit request: by row count
     }
     if (variant == 0) {
         // measured per shape (scripts/gemm_bench.py): where 256x256 tiles fill the chip (N % 256 == 0, >= 192 tiles)
@@ -1895,10 +1961,10 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 18) {
-        GP_REQUIRE(smallm_ok, "gp_gemm: variant 18 needs a plain fp16 GEMM / conv (fp16 out, no split-K, no fused GroupNorm), N %% 32 == 0, M %% 16 == 0");
-        const bool two = d->M % 32 == 0 && d->M > smallm_one_tile_max();      // 32-row tiles once 16-row tiles alone fill the chip
-        if (d->KH > 0) { if (two) launch_smallm<2, 2, true>(p, s); else launch_smallm<1, 2, true>(p, s); }
-        else { if (two) launch_smallm<2, 2, false>(p, s); else launch_smallm<1, 2, false>(p, s); }
+        GP_REQUIRE(smallm_ok, "gp_gemm: variant 18 needs a plain fp16 GEMM / conv (fp16 out, no split-K), N %% 32 == 0, M %% 16 == 0 (%% 64 with fused GroupNorm statistics)");
+        if (d->gn_partial) { if (d->KH > 0) launch_smallm<4, 2, true, true>(p, s); else launch_smallm<4, 2, false, true>(p, s); }
+        else if (d->KH > 0) { if (sm_mt == 4) launch_smallm<4, 2, true, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, true, false>(p, s); else launch_smallm<1, 2, true, false>(p, s); }
+        else { if (sm_mt == 4) launch_smallm<4, 2, false, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, false, false>(p, s); else launch_smallm<1, 2, false, false>(p, s); }
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 16) {

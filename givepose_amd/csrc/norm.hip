@@ -1191,9 +1191,13 @@ static long dw_narrow_below() {   // strip kernel: 2 pixels per thread when 8 wo
     static const long k = [] { const char* e = getenv("GP_DW_NARROW_BELOW"); return e ? atol(e) : 128l; }();
     return k;
 }
-static long dw_mfma_min_wgs() {   // fewest workgroups (4 x 16-pixel tiles) that still go to the MFMA kernel (GP_DW_MFMA_MIN: A/B)
-    static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : 0l; }();
-    return k;
+// fewest workgroups (4 x 16-pixel tiles) that still go to the MFMA kernel: its workgroups live ~16 us whatever the batch (weight
+// fragments, halo pipeline), the strip kernel at 2 pixels per thread ~9.5 us while it fits the chip (scripts/dw_small_ab.py, hipGraph
+// chains: C = 512 15.9 vs 9.5 us at 1-4 crops, 16.4 vs 14.6 at 16; C = 256 10.4 vs 9.5 at 1 crop, 10.6 vs 11.5 at 4; C = 128: MFMA
+// always).  GP_DW_MFMA_MIN=<n>: one threshold for every C (A/B).
+static long dw_mfma_min_wgs(int C) {
+    static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : -1l; }();
+    return k >= 0 ? k : C == 512 ? 65 : C == 256 ? 33 : 0;
 }
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
@@ -1222,7 +1226,7 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && H % 4 == 0 && W % 16 == 0 &&
-        (C == 128 || C == 256 || C == 512) && (long)B * (H / 4) * (W / 16) >= dw_mfma_min_wgs()) {
+        (C == 128 || C == 256 || C == 512) && (long)B * (H / 4) * (W / 16) >= dw_mfma_min_wgs(C)) {
         if (C == 128) launch_dw7_mfma<1, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if (C == 256) launch_dw7_mfma<2, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if ((long)B * (H / 4) * (W / 16) >= 512 || dw_single_buffer()) launch_dw7_mfma<4, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);

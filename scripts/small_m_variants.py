@@ -1,7 +1,7 @@
 """GEMM-class shapes of PoseNet at B = 1 (latency_b1): every schedule that accepts the shape, timed as a hipGraph of 24
 dependent launches (the launch chain of the real step: no host overhead between them), interleaved medians."""
 import os, sys, statistics, torch
-os.environ["GP_GEMM_SMALLM_MAX"] = "0"       # 'auto' = the tile kernels' choice (+ the caller's split-K); variant 18 explicitly
+os.environ["GP_GEMM_SMALLM_MB"] = "0"       # 'auto' = the tile kernels' choice (+ the caller's split-K); variant 18 explicitly
 sys.path.insert(0, ".")
 from givepose_amd import ops
 

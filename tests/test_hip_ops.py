@@ -187,7 +187,9 @@ def test_gemm_small_m_latency_variant():
     bitwise reproducible, with split-K requests ignored."""
     o = ops()
     dt = torch.float16
-    for (M, N, K) in [(256, 2048, 512), (256, 512, 2048), (64, 1024, 4096), (1024, 512, 2048), (16, 32, 64), (48, 96, 832), (32, 64, 2304)]:
+    # (rows, columns, K, default route?): the last three exceed the operand-traffic budget of the automatic choice (32- and 64-row tiles)
+    for (M, N, K, auto_route) in [(256, 2048, 512, True), (256, 512, 2048, True), (64, 1024, 4096, True), (512, 2048, 512, True), (16, 32, 64, True),
+                                  (48, 96, 832, True), (32, 64, 2304, True), (1024, 512, 2048, False), (2048, 256, 2048, False), (2112, 64, 576, False)]:
         x, w, b = q(rnd(M, K, seed=161), dt), q(rnd(N, K, seed=162, scale=K ** -0.5), dt), rnd(N, seed=163)
         res, gamma = q(rnd(M, N, seed=164), dt), rnd(N, seed=165)
         lin = x @ w.t() + b
@@ -200,9 +202,10 @@ def test_gemm_small_m_latency_variant():
             o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda(), epilogue=epi, variant=18, ldc=N + 8, **kw)
             assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, K, epi)
             assert float(out[:, N:].abs().max()) == 0.0
-            auto = torch.zeros(M, N + 8, dtype=dt, device="cuda")
-            o.gemm(x.to("cuda", dt), w.to("cuda", dt), auto, bias=b.cuda(), epilogue=epi, ldc=N + 8, splitk=None, **kw)   # default route
-            assert torch.equal(auto, out), (M, N, K, epi)
+            if auto_route:
+                auto = torch.zeros(M, N + 8, dtype=dt, device="cuda")
+                o.gemm(x.to("cuda", dt), w.to("cuda", dt), auto, bias=b.cuda(), epilogue=epi, ldc=N + 8, splitk=None, **kw)   # default route
+                assert torch.equal(auto, out), (M, N, K, epi)
         nob = torch.empty(M, N, dtype=dt, device="cuda")
         o.gemm(x.to("cuda", dt), w.to("cuda", dt), nob, variant=18)
         assert rel_err(nob, x @ w.t()) < TOL[dt]
@@ -225,6 +228,33 @@ def test_gemm_small_m_latency_variant():
         out = o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18)
         assert rel_err(out, ref) < TOL[dt], cfg
         assert torch.equal(o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18), out)
+    # fused GroupNorm statistics (64-row workgroup tiles; 8 and 4 channels per group; plain GEMM and conv): the statistics the kernel
+    # leaves in 64-row chunks normalise its output exactly as a separate statistics pass over that output does
+    for (Bc, HW, N, K, conv) in [(1, 256, 256, 256, None), (2, 64, 128, 512, None), (1, 1024, 256, 2304, 32), (3, 256, 128, 1152, 16)]:
+        G = 32
+        if conv:
+            Cin = K // 9
+            xi = q(rnd(Bc, conv, conv, Cin, seed=174), dt).to("cuda", dt)
+            w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
+            part = torch.zeros(1 << 16, device="cuda")
+            y = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=18, gn=(part, G, HW)).view(Bc, HW, N)
+            y7 = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW)).view(Bc, HW, N)
+        else:
+            xi = q(rnd(Bc * HW, K, seed=174), dt).to("cuda", dt)
+            w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
+            part = torch.zeros(1 << 16, device="cuda")
+            y = torch.empty(Bc, HW, N, dtype=dt, device="cuda")
+            o.gemm(xi, w, y.view(-1, N), variant=18, gn=(part, G, HW))
+            y7 = torch.empty_like(y)
+            o.gemm(xi, w, y7.view(-1, N), variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW))
+        assert rel_err(y, y7.float().cpu()) < 2e-3, (Bc, HW, N, K)
+        gw, gb = (1 + 0.1 * rnd(N, seed=176)).cuda(), (0.1 * rnd(N, seed=177)).cuda()
+        fused = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, part, fused_stats=True)
+        sep = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, torch.zeros(1 << 16, device="cuda"))
+        # (the fused statistics are of the fp32 values before the fp16 store, the separate pass reads the stored fp16: not bitwise)
+        assert rel_err(fused, sep.float().cpu()) < 2e-3, (Bc, HW, N, K)
+        ref = F.gelu(F.group_norm(y.float().cpu().permute(0, 2, 1), G, gw.cpu(), gb.cpu(), 1e-5)).permute(0, 2, 1)
+        assert rel_err(fused, ref) < TOL[dt], (Bc, HW, N, K)
     # refused loudly where it does not apply: fp32 storage, fp32 output, N not a multiple of 32
     x32, w32 = rnd(64, 128, seed=172).cuda(), rnd(64, 128, seed=173).cuda()
     with pytest.raises(RuntimeError, match="variant 18"):
