@@ -320,7 +320,9 @@ def main():
                                 "trans": float(dmax[1]), "size": float(dmax[2]), "batches_compared": G}
             # every batch of the launch (group 0 and group >= 1) against its own separate forward: median AND worst crop of |dR|, |dt|, |ds|
             # bounded like two numerically equivalent builds of the mode (fp16: tests/test_hip_posenet.py's bounds against the oracle)
-            lim = {"f16": (5e-3, 8e-2, 3e-2, 3e-2)}.get(args.dtype, (2e-5, 1e-4, 2e-5, 2e-5))
+            # (fp16 median: the mode's own median |dR| against the oracle is 3.5-5e-3 and the test bound for it 8e-3; two schedules of the same
+            # arithmetic -- e.g. the small-M latency kernel at B crops against the tile kernels at G x B -- differ by about that)
+            lim = {"f16": (8e-3, 8e-2, 3e-2, 3e-2)}.get(args.dtype, (2e-5, 1e-4, 2e-5, 2e-5))
             grouped_vs_alone["bounds"] = dict(zip(("rot_median_over_crops", "rot_max_over_crops", "trans", "size"), lim))
             grouped_vs_alone["within_bound"] = bool(bit or (float(dmax[0]) < lim[0] and float(dmax[3]) < lim[1] and float(dmax[1]) < lim[2] and float(dmax[2]) < lim[3]))
         if coll:
@@ -328,13 +330,16 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             same = bool(int(tt))
         line["overlap_check"] = {"slots": NF, "batches_per_launch": G, "ranks": world, "poses_bitwise_equal_to_serial_replay": bool(same)}
+        why = None if same else "overlapped batches did not reproduce their serial replay bit for bit"
         if grouped_vs_alone is not None:
             line["overlap_check"]["grouped_vs_separate_batches"] = grouped_vs_alone
+            if same and not grouped_vs_alone["within_bound"]:
+                why = "the batches of a grouped launch differ from their separate forwards by more than two equivalent schedules may (overlap_check.grouped_vs_separate_batches)"
             same = same and grouped_vs_alone["within_bound"]
         if not same:
             line["value"] = None
-            line["invalid"] = "overlapped batches did not reproduce their serial replay bit for bit"
-            note("FAILED: overlapped batches did not reproduce the serial replay bit for bit")
+            line["invalid"] = why
+            note("FAILED: " + why)
             if rank == 0:
                 print(json.dumps(line), flush=True)
             if coll:
@@ -507,18 +512,19 @@ def main():
 
     if rank == 0:
         note("h2d legs done")
-    # ---------------- latency at the batch evaluate.py feeds when a frame holds one detection (hipGraph replay, B = 1)
+    # ---------------- latency at the batches evaluate.py feeds (the detections of ONE frame: evaluation/evaluate.py:89-117), hipGraph replay
     if rank == 0 and world == 1 and not args.no_roofline and args.dtype == "f16":
         netl = PoseNet(cfg, seed=0, use_graph=not args.no_graph, inflight=1, **mode).to(dev)
-        one = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_batch(1, seed=5).items()}
-        for _ in range(4):
-            netl.forward_device(one, dev)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            netl.forward_device(one, dev)
-        torch.cuda.synchronize(dev)
-        line["latency_b1"] = {"ms": round((time.perf_counter() - t0) / 50 * 1e3, 3), "note": "B = 1 forward, hipGraph replay, back to back"}
+        for Bl in (1, 4):
+            few = {k: torch.from_numpy(v).to(dev) for k, v in synth.synth_batch(Bl, seed=5).items()}
+            for _ in range(4):
+                netl.forward_device(few, dev)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                netl.forward_device(few, dev)
+            torch.cuda.synchronize(dev)
+            line[f"latency_b{Bl}"] = {"ms": round((time.perf_counter() - t0) / 50 * 1e3, 3), "note": f"B = {Bl} forward, hipGraph replay, back to back"}
         del netl
     # ---------------- CPU baseline: the oracle on all host cores, bounded sample (B=64 and B=1, median);
     # its B = 64 outputs on slot 0's batch are the reference the `vs_reference` objects are measured against

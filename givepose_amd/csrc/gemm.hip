@@ -1590,8 +1590,8 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
 template <int MT, int NT, int KCH, bool CONV, bool GN>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
     static_assert(!GN || (MT == 4 && NT == 2), "fused GroupNorm statistics: one workgroup = one 64-row chunk x 32 columns");
-    __shared__ f32x4 red[4][MT * NT][64];
-    __shared__ float gred[4][4][2];
+    extern __shared__ __attribute__((aligned(16))) char smallm_lds[];           // 4 waves x MT NT tiles x 64 lanes x 16 B (<= 32 KB)
+    f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(smallm_lds);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;     // (wave stays a vector value: the conv's tap state in SGPRs spilled them)
     const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
     const int nk = p.K >> 5;
@@ -1624,8 +1624,9 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
         const int m = m0 + mt * 16 + r;
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo, b = m / hw, rem = m - b * hw;
-            py[mt] = rem / p.Wo;
-            px[mt] = rem - py[mt] * p.Wo;
+            const int oy = rem / p.Wo;
+            py[mt] = oy * p.stride - p.pad;                 // input row / column of filter tap (0, 0)
+            px[mt] = (rem - oy * p.Wo) * p.stride - p.pad;
             xrow[mt] = reinterpret_cast<const half_t*>(p.X) + ((long)b * p.H * p.Win) * p.Cin + q * 8;
         } else {
             py[mt] = px[mt] = 0;
@@ -1633,6 +1634,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
         }
     }
     const int cpt = CONV ? p.Cin >> 5 : 1;      // K steps per filter tap
+    const int hm1 = p.H - 1, wm1 = p.Win - 1;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1658,11 +1660,11 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (CONV) {
                     // (steps past the range: some tap past the last one -- in the image or masked, never used)
-                    const int iy = py[mt] * p.stride - p.pad + dy, ix = px[mt] * p.stride - p.pad + dx;
+                    const int iy = py[mt] + dy, ix = px[mt] + dx;
                     // out-of-image taps: the load goes to pixel (0, 0) and is masked with a per-lane word built by integer arithmetic
                     // (sign bit of iy | H-1-iy | ix | W-1-ix): a compare + select keeps one 64-bit lane mask per fragment in
                     // SGPRs until the load lands -- 36 of them in the 64-row tile spilled SGPRs
-                    const int keep = ~((iy | (p.H - 1 - iy) | ix | (p.Win - 1 - ix)) >> 31);
+                    const int keep = ~((iy | (hm1 - iy) | ix | (wm1 - ix)) >> 31);
                     const half_t* src = xrow[mt] + ((long)(iy & keep) * p.Win + (ix & keep)) * p.Cin + c0;
                     pf_u32x4 u = *reinterpret_cast<const pf_u32x4*>(src);
                     u &= pf_u32x4{(unsigned)keep, (unsigned)keep, (unsigned)keep, (unsigned)keep};
@@ -1675,6 +1677,9 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
                 if (++cc == cpt) { cc = 0; if (++dx == p.KW) { dx = 0; ++dy; } }
             }
         }
+        // every load of the round is issued before the first MFMA: left alone the scheduler interleaves them to save registers
+        // (136 of the 192 the fragments need), which turns the one memory round trip the kernel is built around into several
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KCH; ++s) {
             if (kb + s < k_hi) {                          // wave-uniform
@@ -1710,6 +1715,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
         }
     }
     if constexpr (GN) {
+        __shared__ float gred[4][4][2];
         // fused GroupNorm statistics: (sum, sum of squares) of this 64-row chunk per channel group, in the tile kernels' layout
         // (B, HW / 64, G, 2).  Wave w finished m-tiles w / 2 and w / 2 + 2 of n-tile w % 2: 16 rows by shuffle, the group's second
         // 4-column quad (8 channels per group) by shuffle, the two waves of an n-tile through LDS in fixed order.
@@ -1734,18 +1740,29 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
 template <int MT, int NT, bool CONV, bool GN>
 static void launch_smallm(const GemmKP& p, hipStream_t s) {
     // fragments in flight: (MT + NT) x KCH x 4 registers <= 256 (one wave per SIMD); convs: 9 (3 x 3 x Cin / 128 steps per wave come
-    // in nines, and 16 unrolled steps of scalar tap state spilled SGPRs)
-    constexpr int KMAX = (CONV || MT + NT > 4) ? 9 : 16;
+    // in nines, and 16 unrolled steps of tap state spilled SGPRs); conv + fused GroupNorm statistics: 6 (9 spilled two SGPRs)
+    constexpr int KMAX = (CONV && GN) ? 6 : (CONV || MT + NT > 4) ? 9 : 16;
     const int per = (p.K / 32 + 3) / 4, rounds = (per + KMAX - 1) / KMAX, kch = (per + rounds - 1) / rounds;
     const dim3 grid(p.N / (16 * NT), p.M / (16 * MT));
-#define GP_SM(KCH) hipLaunchKernelGGL((gemm_smallm_kernel<MT, NT, (KCH) <= KMAX ? (KCH) : KMAX, CONV, GN>), grid, dim3(256), 0, s, p)
+    constexpr int LDS = 4 * MT * NT * 1024;
+#define GP_SM(KCH)                                                                                                              \
+    do {                                                                                                                        \
+        auto kfn = gemm_smallm_kernel<MT, NT, (KCH) <= KMAX ? (KCH) : KMAX, CONV, GN>;                                          \
+        if constexpr (LDS > 48 * 1024) {                                                                                        \
+            static bool attr = false;                                                                                           \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
+        }                                                                                                                       \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), LDS, s, p);                                                                    \
+    } while (0)
     if (kch <= 2) { GP_SM(2); return; }
     if (kch <= 4) { GP_SM(4); return; }
-    if constexpr (!CONV) {          // (the 8-step conv instantiation of the 64-row tile spilled SGPRs: convs go 2 / 4 / 9)
+    if constexpr (!CONV) {          // (the 8-step conv instantiation of the 64-row tile spilled SGPRs: convs go 2 / 4 / 9, or 2 / 4 / 6)
         if (kch <= 8) { GP_SM(8); return; }
     }
-    if (kch <= 9) GP_SM(9);
-    else GP_SM(KMAX);
+    if constexpr (KMAX >= 9) {
+        if (kch <= 9) { GP_SM(9); return; }
+    }
+    GP_SM(KMAX);
 #undef GP_SM
 }
 
@@ -1797,9 +1814,9 @@ static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the pi
     return k;
 }
 
-static long smallm_max_bytes() {   // most L2 -> CU operand traffic a launch of the latency kernel (variant 18) may have; GP_GEMM_SMALLM_MB: A/B, 0 = never
-    static const long k = [] { const char* e = getenv("GP_GEMM_SMALLM_MB"); return (e ? atol(e) : 72l) << 20; }();
-    return k;
+static bool smallm_enabled() {   // GP_GEMM_SMALLM=0: A/B switch, keeps the latency kernel (variant 18) out of the automatic choice
+    static const bool on = [] { const char* e = getenv("GP_GEMM_SMALLM"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 static long pp_min_tiles() {
@@ -1898,7 +1915,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          ((size_t)d->C & 7) == 0 && ((size_t)d->X & 15) == 0 && ((size_t)d->W & 15) == 0 &&
                          (!d->bias || ((size_t)d->bias & 15) == 0);
     // few rows (the detections of one frame): the latency kernel (variant 18), whatever split-K factor the caller worked out for the
-    // tile kernels.  GP_GEMM_SMALLM_MAX: largest M that goes there (A/B switch; 0 = never)
+    // tile kernels.  GP_GEMM_SMALLM=0 keeps it out of the automatic choice (A/B switch)
     const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
                            (!d->gn_partial || (d->M % 64 == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
                            d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
@@ -1907,18 +1924,29 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
-    // workgroup tile of the latency kernel: 16 MT x 32 with the smallest MT in {1, 2, 4} whose operand traffic -- every workgroup
-    // reads its (16 MT + 32) rows of K halfs from L2 -- stays below what the L2 delivers in the time of a launch (measured,
-    // scripts/small_m_variants.py: ~8 us per launch up to ~50 MB, 17-25 us at 130-200 MB).  None: the tile kernels.
+    // Workgroup tile of the latency kernel: (16 MT) x 32, MT in {1, 2, 4}, by a cost model fitted to scripts/small_m_variants.py
+    // (profiles/r04_small_m_tiles.txt; hipGraph chains, 1-8 crops, K 512-4096): a workgroup moves its (16 MT + 32) rows of K halfs
+    // at ~36 KB/us (the MFMA-layout loads touch sixteen 64-byte segments per quarter wave: 15 B/clk/CU), workgroups beyond one
+    // per CU queue up, + 2.6 us.  The tile kernels (with the caller's split-K) cost ~9 us + K / 170, never more than ~21:
+    // the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm statistics need the 64-row tile.
     int sm_mt = 0;
-    if (smallm_ok) {
-        for (int mt = d->gn_partial ? 4 : 1; mt <= 4 && !sm_mt; mt *= 2)     // fused GroupNorm statistics: 64-row workgroup tiles
-            if (d->M % (16 * mt) == 0 && (double)(d->M / (16 * mt)) * (d->N / 32) * (16 * mt + 32) * d->K * 2.0 <= (double)smallm_max_bytes()) sm_mt = mt;
+    if (smallm_ok && smallm_enabled()) {
+        double best = 1e30;
+        for (int mt = d->gn_partial ? 4 : 1; mt <= 4; mt *= 2) {
+            if (d->M % (16 * mt)) continue;
+            const double wgs = (double)(d->M / (16 * mt)) * (d->N / 32), kb_per_wg = (16.0 * mt + 32.0) * d->K * 2.0 / 1024.0;
+            const double t = 2.6 + (wgs > 256.0 ? wgs / 256.0 : 1.0) * kb_per_wg / 36.0;
+            if (t < best) { best = t; sm_mt = mt; }
+        }
+        const double tile = 9.0 + d->K / 170.0;
+        if (best > (tile < 21.0 ? tile : 21.0)) sm_mt = 0;
     }
     if ((variant == 0 && sm_mt) || variant == 18) {
         variant = 18;
         p.splitk = 1;
         if (!sm_mt) sm_mt = d->M % 64 == 0 && (d->M >= 2048 || d->gn_partial) ? 4 : d->M % 32 == 0 && d->M > 512 ? 2 : 1;     // explicit request: by row count
+        // variants 218 / 318 / 418: the tile forced to 16 x 32 / 32 x 32 / 64 x 32 (tests, scripts/small_m_variants.py)
+        if (p.dbg >= 2 && p.dbg <= 4 && !d->gn_partial && d->M % (8 << (p.dbg - 1)) == 0) sm_mt = 1 << (p.dbg - 2);
     }
     if (variant == 0) {
         // measured per shape (scripts/gemm_bench.py): where 256x256 tiles fill the chip (N % 256 == 0, >= 192 tiles)

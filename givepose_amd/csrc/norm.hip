@@ -1193,11 +1193,11 @@ static long dw_narrow_below() {   // strip kernel: 2 pixels per thread when 8 wo
 }
 // fewest workgroups (4 x 16-pixel tiles) that still go to the MFMA kernel: its workgroups live ~16 us whatever the batch (weight
 // fragments, halo pipeline), the strip kernel at 2 pixels per thread ~9.5 us while it fits the chip (scripts/dw_small_ab.py, hipGraph
-// chains: C = 512 15.9 vs 9.5 us at 1-4 crops, 16.4 vs 14.6 at 16; C = 256 10.4 vs 9.5 at 1 crop, 10.6 vs 11.5 at 4; C = 128: MFMA
-// always).  GP_DW_MFMA_MIN=<n>: one threshold for every C (A/B).
+// chains: C = 512 15.9 vs 9.5 us at 1-4 crops; C = 256 10.4 vs 9.5 at 1 crop, 10.6 vs 11.5 at 4; C = 128: MFMA always.  Inside the
+// network (scripts/b1_trace.py) the strip kernel wins up to 12 crops at C = 512 -- 3.25 vs 3.37 ms -- and loses at 16: 4.04 vs 3.62).  GP_DW_MFMA_MIN=<n>: one threshold for every C (A/B).
 static long dw_mfma_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : -1l; }();
-    return k >= 0 ? k : C == 512 ? 65 : C == 256 ? 33 : 0;
+    return k >= 0 ? k : C == 512 ? 52 : C == 256 ? 33 : 0;
 }
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();

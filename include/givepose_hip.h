@@ -126,7 +126,7 @@ typedef struct gp_gemm_desc {
     /* conv mode */
     int B, H, Win, Cin, KH, KW, stride, pad, Ho, Wo;
     int dtype;
-    /* optional fused GroupNorm statistics of the OUTPUT (large-tile variants, no split-K): per 64 output rows and
+    /* optional fused GroupNorm statistics of the OUTPUT (large-tile variants and variant 18, no split-K): per 64 output rows and
      * channel group (sum, sum of squares) -> gn_partial (M/64, gn_groups, 2) fp32, i.e. (B, HW/64, G, 2) when
      * M = B*gn_hw; consumed by gp_groupnorm_apply(..., chunks = gn_hw/64). NULL = off. */
     float* gn_partial;
@@ -135,7 +135,10 @@ typedef struct gp_gemm_desc {
                   * tile (the split-K carrier), 5 / 9 = its 4-stage forms, 7 = 128x128 software-pipelined, two workgroups per
                   * CU, 2 / 8 = 256x128, 3 = 256x256, 10 / 11 / 12 = ping-pong 256x256 / 128x256 / 5-stage, 13 = 3x3 window
                   * conv (Cout 256), 16 / 17 = K 512 with the weight slice resident in registers (17: 16-byte stores, needs ldc % 8 == 0 and a
-                  * 16-byte aligned C; the default of stage-2 fc1).  + 100 n: timing ablations. */
+                  * 16-byte aligned C; the default of stage-2 fc1), 18 = the small-M latency kernel (few rows -- the detections of one
+                  * frame: fp16 in / out, N % 32 == 0, M % 16 == 0 (% 64 with gn_partial), plain GEMM or conv; chosen by variant 0 when its
+                  * estimate beats the tile kernels'; a split-K request is ignored; 218 / 318 / 418 force the 16 / 32 / 64-row tile).
+                  * + 100 n otherwise: timing ablations. */
     /* GP_EPI_LNFOLD_GELU only: ln_stats (M, 2, ln_nslab) fp32 partial (sum, sum of squares) of each X row over
      * ln_nslab channel slabs; ln_colsum (N) fp32; ln_eps.  Requires M % 256 == 0, N % 256 == 0, fp16 output. */
     const float* ln_stats;

@@ -1,7 +1,7 @@
 """GEMM-class shapes of PoseNet at B = 1 (latency_b1): every schedule that accepts the shape, timed as a hipGraph of 24
 dependent launches (the launch chain of the real step: no host overhead between them), interleaved medians."""
 import os, sys, statistics, torch
-os.environ["GP_GEMM_SMALLM_MB"] = "0"       # 'auto' = the tile kernels' choice (+ the caller's split-K); variant 18 explicitly
+os.environ["GP_GEMM_SMALLM"] = "0"       # 'auto' = the tile kernels' choice (+ the caller's split-K); variant 18 explicitly
 sys.path.insert(0, ".")
 from givepose_amd import ops
 
@@ -42,7 +42,7 @@ for name, M, N, K, epi in gemms:
     gamma, b = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
     kw = dict(gamma=gamma, residual=res) if epi == ops.EPI_SCALE_RES else {}
     r = {}
-    for v, sk in ((0, None), (7, 1), (4, 1), (5, 1), (9, 1), (8, 1), (2, 1), (16, 1), (17, 1), (18, 1), (4, 2), (4, 4), (4, 8), (4, 16)):
+    for v, sk in ((0, None), (7, 1), (4, 1), (5, 1), (9, 1), (8, 1), (2, 1), (16, 1), (17, 1), (218, 1), (318, 1), (418, 1), (4, 2), (4, 4), (4, 8), (4, 16)):
         try:
             r[f"v{v}" + (f" splitK{sk}" if sk and sk > 1 else "") if v else "auto"] = round(graph_time(lambda: ops.gemm(x, w, out, bias=b, epilogue=epi, variant=v, splitk=sk, **kw)), 1)
         except Exception as e:
@@ -55,7 +55,7 @@ for name, R in convs:
     out = torch.empty(B, R, R, 256, device="cuda", dtype=torch.half)
     part = torch.zeros(1 << 16, device="cuda")
     r = {}
-    for v, sk, gn in ((0, None, True), (0, None, False), (18, 1, False), (7, 1, True), (5, 1, True), (9, 1, True), (4, 1, True), (8, 1, True), (13, 1, True),
+    for v, sk, gn in ((0, None, True), (0, None, False), (18, 1, True), (218, 1, False), (318, 1, False), (418, 1, False), (7, 1, True), (5, 1, True), (9, 1, True), (4, 1, True), (8, 1, True), (13, 1, True),
                       (4, 2, False), (4, 3, False), (4, 6, False), (4, 9, False), (4, 18, False)):
         key = (f"v{v}" if v else "auto") + (f" splitK{sk}" if sk and sk > 1 else "") + (" +gn" if gn else "")
         try:

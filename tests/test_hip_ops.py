@@ -189,7 +189,7 @@ def test_gemm_small_m_latency_variant():
     dt = torch.float16
     # (rows, columns, K, default route?): the last three exceed the operand-traffic budget of the automatic choice (32- and 64-row tiles)
     for (M, N, K, auto_route) in [(256, 2048, 512, True), (256, 512, 2048, True), (64, 1024, 4096, True), (512, 2048, 512, True), (16, 32, 64, True),
-                                  (48, 96, 832, True), (32, 64, 2304, True), (1024, 512, 2048, False), (2048, 256, 2048, False), (2112, 64, 576, False)]:
+                                  (48, 96, 832, True), (32, 64, 2304, True), (1024, 512, 2048, True), (1024, 2048, 512, False), (2048, 256, 2048, False), (2112, 64, 576, False)]:
         x, w, b = q(rnd(M, K, seed=161), dt), q(rnd(N, K, seed=162, scale=K ** -0.5), dt), rnd(N, seed=163)
         res, gamma = q(rnd(M, N, seed=164), dt), rnd(N, seed=165)
         lin = x @ w.t() + b
@@ -209,6 +209,11 @@ def test_gemm_small_m_latency_variant():
         nob = torch.empty(M, N, dtype=dt, device="cuda")
         o.gemm(x.to("cuda", dt), w.to("cuda", dt), nob, variant=18)
         assert rel_err(nob, x @ w.t()) < TOL[dt]
+        for forced, rows in ((218, 16), (318, 32), (418, 64)):      # every tile height forced: the same sums in the same order
+            if M % rows == 0:
+                t = torch.empty(M, N, dtype=dt, device="cuda")
+                o.gemm(x.to("cuda", dt), w.to("cuda", dt), t, variant=forced)
+                assert torch.equal(t, nob), (M, N, K, forced)
     # X as a column slice of a wider matrix (ldx), in-place residual (fc2 of a ConvNeXt block: out is the residual)
     M, K, N = 256, 512, 512
     xw, w = q(rnd(M, 2 * K, seed=166), dt).cuda().half(), q(rnd(N, K, seed=167, scale=K ** -0.5), dt).cuda().half()
