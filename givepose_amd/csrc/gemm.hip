@@ -1587,12 +1587,25 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
 // Operand roles as everywhere in this file: W is the MFMA A operand and X the B operand, so a lane ends up with 4 consecutive
 // n of one row m.  3 x 3 / stride 1 / pad 1 convs (the heads' 256 -> 256 convs at 16 x 16 .. 64 x 64) run through the same kernel:
 // a row is an output pixel, a 32-wide K step lies inside one filter tap (Cin % 32 == 0), out-of-image taps load nothing.
+// a fragment loaded row-major over the lanes (lane l: row l / 4, chunk l % 4) -> the MFMA operand layout (lane l: row l % 16, chunk l / 16):
+// MFMA lane (r, q) pulls the four dwords of lane 4 r + q through the LDS crossbar (no LDS memory involved)
+__device__ __forceinline__ half8 to_mfma_lanes(half8 v, int pull) {
+    pf_u32x4 u = __builtin_bit_cast(pf_u32x4, v);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) u[d] = (unsigned)__builtin_amdgcn_ds_bpermute(pull, (int)u[d]);
+    return __builtin_bit_cast(half8, u);
+}
+
 template <int MT, int NT, int KCH, bool CONV, bool GN>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
     static_assert(!GN || (MT == 4 && NT == 2), "fused GroupNorm statistics: one workgroup = one 64-row chunk x 32 columns");
     extern __shared__ __attribute__((aligned(16))) char smallm_lds[];           // 4 waves x MT NT tiles x 64 lanes x 16 B (<= 32 KB)
     f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(smallm_lds);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;     // (wave stays a vector value: the conv's tap state in SGPRs spilled them)
+    // LOADS: lane l fetches row l / 4, 16-byte chunk l % 4 of a K step -- four neighbouring lanes read 64 contiguous bytes, a quarter
+    // wave 4 rows (in the MFMA layout, row l % 16 / chunk l / 16, a quarter wave touches sixteen 16-byte pieces of sixteen rows:
+    // measured 15 B/clk/CU).  One ds_bpermute per dword then hands MFMA lane (r, q) the data lane 4 r + q loaded.
+    const int rl = lane >> 2, ql = lane & 3, pull = (4 * r + q) * 4;
     const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
     const int nk = p.K >> 5;
     const int per = (nk + 3) >> 2, k_lo = wave * per, k_hi = min(nk, k_lo + per);
@@ -1616,21 +1629,21 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
     // ---- operand rows
     const half_t* wrow[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wrow[nt] = reinterpret_cast<const half_t*>(p.W) + (long)(n0 + nt * 16 + r) * p.K + q * 8;
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = reinterpret_cast<const half_t*>(p.W) + (long)(n0 + nt * 16 + rl) * p.K + ql * 8;
     const half_t* xrow[MT];
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + mt * 16 + r;
+        const int m = m0 + mt * 16 + rl;
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo, b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wo;
             py[mt] = oy * p.stride - p.pad;                 // input row / column of filter tap (0, 0)
             px[mt] = (rem - oy * p.Wo) * p.stride - p.pad;
-            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + ((long)b * p.H * p.Win) * p.Cin + q * 8;
+            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + ((long)b * p.H * p.Win) * p.Cin + ql * 8;
         } else {
             py[mt] = px[mt] = 0;
-            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + (long)m * p.ldx + q * 8;
+            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + (long)m * p.ldx + ql * 8;
         }
     }
     const int cpt = CONV ? p.Cin >> 5 : 1;      // K steps per filter tap
@@ -1683,11 +1696,16 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
 #pragma unroll
         for (int s = 0; s < KCH; ++s) {
             if (kb + s < k_hi) {                          // wave-uniform
+                half8 wm[NT], xm[MT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wm[nt] = to_mfma_lanes(wf[s][nt], pull);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xm[mt] = to_mfma_lanes(xf[s][mt], pull);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][nt], xf[s][mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[nt], xm[mt], acc[mt][nt], 0, 0, 0);
             }
         }
     }
@@ -1925,21 +1943,24 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
     // Workgroup tile of the latency kernel: (16 MT) x 32, MT in {1, 2, 4}, by a cost model fitted to scripts/small_m_variants.py
-    // (profiles/r04_small_m_tiles.txt; hipGraph chains, 1-8 crops, K 512-4096): a workgroup moves its (16 MT + 32) rows of K halfs
-    // at ~36 KB/us (the MFMA-layout loads touch sixteen 64-byte segments per quarter wave: 15 B/clk/CU), workgroups beyond one
-    // per CU queue up, + 2.6 us.  The tile kernels (with the caller's split-K) cost ~9 us + K / 170, never more than ~21:
-    // the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm statistics need the 64-row tile.
+    // (profiles/r04_small_m_tiles.txt; hipGraph chains, 1-8 crops, K 512-4096): ~2.6 us of launch + epilogue; ONE workgroup moves
+    // its (16 MT + 32) rows of K halfs in ~1 us + KB / 60; a CU that holds several workgroups sustains ~45 KB/us; the 64-row
+    // tile pays ~1.5 us more (two output tiles per wave, 32 KB through LDS).  The tile kernels (with the caller's split-K)
+    // cost ~9 us + K / 170, never more than ~21 -- ~30 with fused GroupNorm statistics (their 128 x 128 tile + statistics epilogue is
+    // 32 us flat up to 4 096 rows): the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm
+    // statistics need the 64-row tile.
     int sm_mt = 0;
     if (smallm_ok && smallm_enabled()) {
         double best = 1e30;
         for (int mt = d->gn_partial ? 4 : 1; mt <= 4; mt *= 2) {
             if (d->M % (16 * mt)) continue;
             const double wgs = (double)(d->M / (16 * mt)) * (d->N / 32), kb_per_wg = (16.0 * mt + 32.0) * d->K * 2.0 / 1024.0;
-            const double t = 2.6 + (wgs > 256.0 ? wgs / 256.0 : 1.0) * kb_per_wg / 36.0;
+            const double one = 1.0 + kb_per_wg / 60.0, many = wgs / 256.0 * kb_per_wg / 45.0;
+            const double t = 2.6 + (one > many ? one : many) + (mt == 4 ? 1.5 : 0.0);
             if (t < best) { best = t; sm_mt = mt; }
         }
-        const double tile = 9.0 + d->K / 170.0;
-        if (best > (tile < 21.0 ? tile : 21.0)) sm_mt = 0;
+        const double tile = d->gn_partial ? 30.0 : 9.0 + d->K / 170.0 < 21.0 ? 9.0 + d->K / 170.0 : 21.0;
+        if (best > tile) sm_mt = 0;
     }
     if ((variant == 0 && sm_mt) || variant == 18) {
         variant = 18;
