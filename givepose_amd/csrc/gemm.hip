@@ -1832,6 +1832,10 @@ static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the pi
     return k;
 }
 
+static double smallm_tile_bias() {   // GP_GEMM_SMALLM_BIAS=<us>: added to the tile kernels' estimate in the choice above (A/B switch)
+    static const double b = [] { const char* e = getenv("GP_GEMM_SMALLM_BIAS"); return e ? atof(e) : 0.0; }();
+    return b;
+}
 static bool smallm_enabled() {   // GP_GEMM_SMALLM=0: A/B switch, keeps the latency kernel (variant 18) out of the automatic choice
     static const bool on = [] { const char* e = getenv("GP_GEMM_SMALLM"); return !(e && e[0] == '0'); }();
     return on;
@@ -1959,7 +1963,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             const double t = 2.6 + (one > many ? one : many) + (mt == 4 ? 1.5 : 0.0);
             if (t < best) { best = t; sm_mt = mt; }
         }
-        const double tile = d->gn_partial ? 30.0 : 9.0 + d->K / 170.0 < 21.0 ? 9.0 + d->K / 170.0 : 21.0;
+        const double tile = (d->gn_partial ? 30.0 : 9.0 + d->K / 170.0 < 21.0 ? 9.0 + d->K / 170.0 : 21.0) + smallm_tile_bias();
         if (best > tile) sm_mt = 0;
     }
     if ((variant == 0 && sm_mt) || variant == 18) {
