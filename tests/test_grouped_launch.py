@@ -19,7 +19,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from rot_cond import rot_error_bound  # noqa: E402
+from givepose_amd.rot_cond import rot_error_bound  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -161,13 +161,13 @@ def test_grouped_launch_bs128_matches_oracle_per_batch(oracle_2x64, mode):
         else:
             # The distribution of |dR| over the crops, the rot6d logits (what the network computes, before the 6-D -> R
             # normalisation) relative to their scale, and EVERY crop's |dR| against what its own logit error and conditioning
-            # explain (tests/rot_cond.py).  The plain maximum of |dR| is the worst-conditioned crop of the batch and moves with
+            # explain (givepose_amd/rot_cond.py).  The plain maximum of |dR| is the worst-conditioned crop of the batch and moves with
             # the batch seed and with every rounding-level change of any kernel (seed 641: 4.3e-2 -> 9.4e-2 when the bilinear
             # blend began to round once instead of twice): it gets no ceiling of its own.
             r6d = dev["rot6d"][sl].float().cpu()
             r6 = float((r6d - ref["rot6d"]).abs().max() / ref["rot6d"].abs().max())
             bound = rot_error_bound(ref["rot6d"], r6d)
-            per_u = (out["rot"][sl].cpu() - ref["rot"]).abs().reshape(64, -1).max(1).values.double()
+            per_u = (dev["rot_allo"][sl].float().cpu().reshape(64, -1) - ref["rot_allo"].reshape(64, -1)).abs().max(1).values.double()   # allocentric: the map the bound is for
             worst = int(per_u.argmax())
             print(f"   rot6d logits rel {r6:.2e}; worst crop {worst}: |dR| {float(per_u[worst]):.3e}, explained up to {float(bound[worst]):.3e}")
             assert r6 < 1.5e-2, (g, r6)

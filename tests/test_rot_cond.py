@@ -1,4 +1,4 @@
-"""The conditioning bound the fp16 parity tests lean on (tests/rot_cond.py), checked against the oracle's own 6-D -> R map."""
+"""The conditioning bound the fp16 parity tests lean on (givepose_amd/rot_cond.py), checked against the oracle's own 6-D -> R map."""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle.posenet_ref import rot6d_to_mat_ref  # noqa: E402
-from rot_cond import rot6d_amplification, rot_error_bound  # noqa: E402
+from givepose_amd.rot_cond import rot6d_amplification, rot_error_bound  # noqa: E402
 
 
 def test_rot_error_bound_holds_for_random_and_badly_conditioned_logits():
