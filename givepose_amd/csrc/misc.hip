@@ -263,7 +263,14 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x
     const int oy = (int)(t % Ho);
     const long b = t / Ho;
     // align_corners=True: src = dst * (in-1)/(out-1)
-    const float sy = bilerp_src((float)(H - 1) / (float)(Ho - 1), oy), sx = bilerp_src((float)(W - 1) / (float)(Wo - 1), ox);
+    float sy, sx;
+    if constexpr (sizeof(T) == 2) {   // fp16 storage: roundings pinned (common.hpp bilerp_*: gp_groupnorm_upsample2x must agree bit for bit)
+        sy = bilerp_src((float)(H - 1) / (float)(Ho - 1), oy);
+        sx = bilerp_src((float)(W - 1) / (float)(Wo - 1), ox);
+    } else {                          // fp32 storage: the plain expressions of rounds 1-3
+        sy = (float)(H - 1) / (float)(Ho - 1) * oy;
+        sx = (float)(W - 1) / (float)(Wo - 1) * ox;
+    }
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
@@ -271,13 +278,19 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ x
     const Vec16<T> v00 = load16<T>(xb + ((long)y0 * W + x0) * C), v01 = load16<T>(xb + ((long)y0 * W + x1) * C),
                    v10 = load16<T>(xb + ((long)y1 * W + x0) * C), v11 = load16<T>(xb + ((long)y1 * W + x1) * C);
     Vec16<T> o;
-    float h0[VEC], h1[VEC];
+    if constexpr (sizeof(T) == 2) {
+        float h0[VEC], h1[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        h0[e] = bilerp_h(hx, v00.get(e), lx, v01.get(e));
-        h1[e] = bilerp_h(hx, v10.get(e), lx, v11.get(e));
+        for (int e = 0; e < VEC; ++e) {
+            h0[e] = bilerp_h(hx, v00.get(e), lx, v01.get(e));
+            h1[e] = bilerp_h(hx, v10.get(e), lx, v11.get(e));
+        }
+        bilerp_v_vec<T>(o, hy, h0, ly, h1);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            o.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
     }
-    bilerp_v_vec<T>(o, hy, h0, ly, h1);
     store16<T>(y + ((b * Ho + oy) * Wo + ox) * C + cs * VEC, o);
 }
 
@@ -293,7 +306,14 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restric
     const int ox = i >> ct_shift, cs = i & (CT - 1);
     if (ox >= Wo) return;
     const int oy = blockIdx.y, b = blockIdx.z;
-    const float sy = bilerp_src((float)(H - 1) / (float)(Ho - 1), oy), sx = bilerp_src((float)(W - 1) / (float)(Wo - 1), ox);
+    float sy, sx;
+    if constexpr (sizeof(T) == 2) {   // fp16 storage: roundings pinned (common.hpp bilerp_*: gp_groupnorm_upsample2x must agree bit for bit)
+        sy = bilerp_src((float)(H - 1) / (float)(Ho - 1), oy);
+        sx = bilerp_src((float)(W - 1) / (float)(Wo - 1), ox);
+    } else {                          // fp32 storage: the plain expressions of rounds 1-3
+        sy = (float)(H - 1) / (float)(Ho - 1) * oy;
+        sx = (float)(W - 1) / (float)(Wo - 1) * ox;
+    }
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
@@ -302,13 +322,19 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restric
     const Vec16<T> v00 = load16<T>(r0 + x0 * C), v01 = load16<T>(r0 + x1 * C), v10 = load16<T>(r1 + x0 * C),
                    v11 = load16<T>(r1 + x1 * C);
     Vec16<T> o;
-    float h0[VEC], h1[VEC];
+    if constexpr (sizeof(T) == 2) {
+        float h0[VEC], h1[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        h0[e] = bilerp_h(hx, v00.get(e), lx, v01.get(e));
-        h1[e] = bilerp_h(hx, v10.get(e), lx, v11.get(e));
+        for (int e = 0; e < VEC; ++e) {
+            h0[e] = bilerp_h(hx, v00.get(e), lx, v01.get(e));
+            h1[e] = bilerp_h(hx, v10.get(e), lx, v11.get(e));
+        }
+        bilerp_v_vec<T>(o, hy, h0, ly, h1);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            o.set(e, hy * (hx * v00.get(e) + lx * v01.get(e)) + ly * (hx * v10.get(e) + lx * v11.get(e)));
     }
-    bilerp_v_vec<T>(o, hy, h0, ly, h1);
     store16p<T>(y, (((long)(b * Ho + oy)) * Wo + ox) * C + cs * VEC, o, pl);
 }
 

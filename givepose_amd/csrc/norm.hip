@@ -722,6 +722,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     store16p<T>(y, row * ldy + cs * VEC, o, pl);
 }
 
+// GroupNorm scale / shift arithmetic.  fp16 storage: every rounding pinned (explicit fma), because gp_groupnorm_upsample2x must agree bit for
+// bit with gp_groupnorm_apply and hipcc contracts `a * b + c` differently from one instantiation to the next.  fp32 storage keeps the
+// plain expressions of rounds 1-3 (nothing has to agree with them, and the parity modes' measured errors stay what they were).
+template <typename T> __device__ __forceinline__ float gn_shift(float mean, float sc, float gb) {
+    if constexpr (sizeof(T) == 2) return __fmaf_rn(-mean, sc, gb);
+    else return gb - mean * sc;
+}
+template <typename T> __device__ __forceinline__ float gn_norm(float v, float sc, float sh) {
+    if constexpr (sizeof(T) == 2) return __fmaf_rn(v, sc, sh);
+    else return v * sc + sh;
+}
 // ---------------------------------------------------------------------------- GroupNorm
 // pixels per block: 256 when that still gives >= 1024 blocks, else 64 (small maps are latency bound)
 static inline int gn_pxb(int B, int HW) { return ((long)B * HW / 256 >= 1024 || HW < 64) ? 256 : 64; }
@@ -843,7 +854,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int e = 0; e < VEC; ++e) {
         const int g = (cs * VEC + e) / cpg;
         sc[e] = st[g][1] * gw[e];
-        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
+        sh[e] = gn_shift<T>(st[g][0], sc[e], gb[e]);
     }
     for (int pb = p0 + pl; pb < p1; pb += 4 * PG) {
         Vec16<T> cur[4];
@@ -860,13 +871,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                 for (int e = 0; e < VEC; e += 2) {
-                    const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(cur[u].get(e), sc[e], sh[e]), __fmaf_rn(cur[u].get(e + 1), sc[e + 1], sh[e + 1])});
+                    const f32x2 g = gelu_poly2(f32x2{gn_norm<T>(cur[u].get(e), sc[e], sh[e]), gn_norm<T>(cur[u].get(e + 1), sc[e + 1], sh[e + 1])});
                     o.set(e, g[0]);
                     o.set(e + 1, g[1]);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(__fmaf_rn(cur[u].get(e), sc[e], sh[e]), act));
+                for (int e = 0; e < VEC; ++e) o.set(e, apply_act(gn_norm<T>(cur[u].get(e), sc[e], sh[e]), act));
             }
             store16p<T>(y, yo + (long)p * ldy, o, plane);
         }
@@ -911,7 +922,7 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
     for (int e = 0; e < VEC; ++e) {
         const int g = (cs * VEC + e) / cpg;
         sc[e] = st[g][1] * gw[e];
-        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
+        sh[e] = gn_shift<T>(st[g][0], sc[e], gb[e]);
     }
     for (int it0 = 0; it0 < iters; it0 += 4) {
         Vec16<T> vq[4];
@@ -933,13 +944,13 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
                 if (act == GP_ACT_GELU && sizeof(T) == 2) {
 #pragma unroll
                     for (int e = 0; e < VEC; e += 2) {
-                        const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(v.get(e), sc[e], sh[e]), __fmaf_rn(v.get(e + 1), sc[e + 1], sh[e + 1])});
+                        const f32x2 g = gelu_poly2(f32x2{gn_norm<T>(v.get(e), sc[e], sh[e]), gn_norm<T>(v.get(e + 1), sc[e + 1], sh[e + 1])});
                         a[e] = g[0];
                         a[e + 1] = g[1];
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) a[e] = apply_act(__fmaf_rn(v.get(e), sc[e], sh[e]), act);
+                    for (int e = 0; e < VEC; ++e) a[e] = apply_act(gn_norm<T>(v.get(e), sc[e], sh[e]), act);
                 }
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
@@ -1097,7 +1108,7 @@ __global__ __launch_bounds__(256) void gn_upsample2x_kernel(const half_t* __rest
     for (int e = 0; e < 8; ++e) {
         const int g = (cs * 8 + e) / cpg;
         sc[e] = st[g][1] * gw[e];
-        sh[e] = __fmaf_rn(-st[g][0], sc[e], gb[e]);      // pinned: the apply kernels must agree bit for bit
+        sh[e] = gn_shift<half_t>(st[g][0], sc[e], gb[e]);
     }
     const half_t* xb = x + ((long)b * H * W) * C + cs * 8;
     const int NSRC = TSY * TS;
@@ -1118,13 +1129,13 @@ __global__ __launch_bounds__(256) void gn_upsample2x_kernel(const half_t* __rest
             if (act == GP_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const f32x2 g = gelu_poly2(f32x2{__fmaf_rn(v[u].get(e), sc[e], sh[e]), __fmaf_rn(v[u].get(e + 1), sc[e + 1], sh[e + 1])});
+                    const f32x2 g = gelu_poly2(f32x2{gn_norm<half_t>(v[u].get(e), sc[e], sh[e]), gn_norm<half_t>(v[u].get(e + 1), sc[e + 1], sh[e + 1])});
                     o.set(e, g[0]);
                     o.set(e + 1, g[1]);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o.set(e, apply_act(__fmaf_rn(v[u].get(e), sc[e], sh[e]), act));
+                for (int e = 0; e < 8; ++e) o.set(e, apply_act(gn_norm<half_t>(v[u].get(e), sc[e], sh[e]), act));
             }
             *reinterpret_cast<uint4*>(gus + ((long)p * CT + cs) * 16) = o.u;
         }
