@@ -71,6 +71,9 @@ template <> __device__ __forceinline__ void mac16<half_t>(float* acc, const Vec1
 }
 
 // ---------------------------------------------------------------------------- dwconv + LN (+act)
+#ifndef DW_STRIP_PD
+#define DW_STRIP_PD 2
+#endif
 // PPT pixels (one strip of a row) per thread: 8 for throughput; 2 where 8 would leave most of the chip idle (the detections of
 // one frame: 256 pixels of a stage-2 map are 8 workgroups at PPT = 8 and 32 at PPT = 2 -- more halo reads, all of them cache hits)
 template <typename T, int KS, int PPT>
@@ -99,7 +102,41 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[p][e] = bv[e];
     }
-    if (valid) {
+    if constexpr (PPT == 2) {
+        // latency form: the input pixels and taps of filter rows kh + 1 .. kh + PD are requested before row kh is multiplied (rolling
+        // window: the seven load -> multiply rounds of the loop below overlap instead of queueing up).  In a hipGraph chain at 1 crop:
+        // 9.5 -> 8.3 us per launch (PD = 1); inside the network PD = 2 is another 1-2 % of a 4-crop forward, PD = 3 nothing more;
+        // requesting the WHOLE 7 x 8 window first was slower (13.4 us)
+        if (valid) {
+            const T* xb = x + (b * H * W) * C + cs * VEC;
+            constexpr int PD = DW_STRIP_PD;      // filter rows in flight ahead of the one being multiplied
+            Vec16<T> in[PD + 1][KS + 1], wv[PD + 1][KS];
+            auto fetch = [&](int kh, Vec16<T> (&dst)[KS + 1], Vec16<T> (&wd)[KS]) {
+                const int hi = h + kh - R;
+                const bool rowok = (unsigned)hi < (unsigned)H;
+#pragma unroll
+                for (int c = 0; c < KS + 1; ++c) {
+                    const int wi = w0 + c - R;
+                    dst[c] = (rowok && (unsigned)wi < (unsigned)W) ? load16<T>(xb + ((long)hi * W + wi) * C) : zero16<T>();
+                }
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) wd[kw] = load16<T>(wt + (long)(kh * KS + kw) * C + cs * VEC);
+            };
+#pragma unroll
+            for (int k0 = 0; k0 < PD && k0 < KS; ++k0) fetch(k0, in[k0 % (PD + 1)], wv[k0 % (PD + 1)]);
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh) {
+                if (kh + PD < KS) fetch(kh + PD, in[(kh + PD) % (PD + 1)], wv[(kh + PD) % (PD + 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    mac16<T>(acc[0], in[kh % (PD + 1)][kw], wv[kh % (PD + 1)][kw]);
+                    mac16<T>(acc[1], in[kh % (PD + 1)][kw + 1], wv[kh % (PD + 1)][kw]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if (valid) {
         const T* xb = x + (b * H * W) * C + cs * VEC;
         for (int kh = 0; kh < KS; ++kh) {
             const int hi = h + kh - R;
