@@ -1950,7 +1950,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // (profiles/r04_small_m_tiles.txt; hipGraph chains, 1-8 crops, K 512-4096): ~2.6 us of launch + epilogue; ONE workgroup moves
     // its (16 MT + 32) rows of K halfs in ~1 us + KB / 60; a CU that holds several workgroups sustains ~45 KB/us; the 64-row
     // tile pays ~1.5 us more (two output tiles per wave, 32 KB through LDS).  The tile kernels (with the caller's split-K)
-    // cost ~9 us + K / 170, never more than ~21 -- ~30 with fused GroupNorm statistics (their 128 x 128 tile + statistics epilogue is
+    // cost ~9 us + K / 160, never more than ~22 -- ~30 with fused GroupNorm statistics (their 128 x 128 tile + statistics epilogue is
     // 32 us flat up to 4 096 rows): the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm
     // statistics need the 64-row tile.
     int sm_mt = 0;
@@ -1963,7 +1963,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             const double t = 2.6 + (one > many ? one : many) + (mt == 4 ? 1.5 : 0.0);
             if (t < best) { best = t; sm_mt = mt; }
         }
-        const double tile = (d->gn_partial ? 30.0 : 9.0 + d->K / 170.0 < 21.0 ? 9.0 + d->K / 170.0 : 21.0) + smallm_tile_bias();
+        const double tile = (d->gn_partial ? 30.0 : 9.0 + d->K / 160.0 < 22.0 ? 9.0 + d->K / 160.0 : 22.0) + smallm_tile_bias();
         if (best > tile) sm_mt = 0;
     }
     if ((variant == 0 && sm_mt) || variant == 18) {
