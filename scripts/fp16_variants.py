@@ -4,7 +4,7 @@ import os, sys, statistics, torch
 sys.path.insert(0, ".")
 from givepose_amd import ops
 
-shapes = [("s2 fc1", 16384, 2048, 512, ops.EPI_GELU, (16, 17, 10, 8, 11, 7)), ("s2 fc2", 16384, 512, 2048, ops.EPI_SCALE_RES, (7, 10, 11, 8, 12)),
+shapes = [("s2 fc1", 16384, 2048, 512, ops.EPI_GELU, (16, 17, 10, 8, 11, 7)), ("s2 fc2", 16384, 512, 2048, ops.EPI_SCALE_RES, (7, 10, 11, 8, 12, 3, 2)),
           ("s3 fc1", 4096, 4096, 1024, ops.EPI_GELU, (7, 10, 11, 8)), ("s3 fc2", 4096, 1024, 4096, ops.EPI_SCALE_RES, (7, 10, 11, 8)),
           ("ds2 (as gemm)", 16384, 512, 1024, ops.EPI_NONE, (7, 10, 11, 8)), ("deconv", 4096, 2304, 1024, ops.EPI_NONE, (7, 10, 11, 8)),
           ("dcn fold L1", 262144, 256, 256, ops.EPI_NONE, (7, 10, 11, 8)), ("dcn out L1", 65536, 256, 256, ops.EPI_NONE, (7, 10, 11, 8))]
