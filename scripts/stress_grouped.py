@@ -8,8 +8,12 @@ from givepose_amd import PoseNet, PoseNetConfig, synth
 REPS = int(os.environ.get("REPS", 200))
 dev = torch.device("cuda")
 skip = ("h0", "h1", "e_in0", "e_in1", "e_in2")
-for name, B, NS, kw, reps in (("fp16 2x(2x64)", 128, 2, dict(dtype=torch.float16, dcn_couple=64), REPS),
-                              ("split 3x64", 64, 3, dict(dtype=torch.float32, split_gemm=True), max(20, REPS // 5))):
+CASES = (("fp16 2x(2x64)", 128, 2, dict(dtype=torch.float16, dcn_couple=64), REPS),
+         ("split 3x64", 64, 3, dict(dtype=torch.float32, split_gemm=True), max(20, REPS // 5)))
+if os.environ.get("SMALL"):     # SMALL=1: the small-batch path (small-M GEMM kernel, 2-pixel strip depth-wise kernel) with three forwards in flight
+    CASES = (("fp16 3x1", 1, 3, dict(dtype=torch.float16), REPS), ("fp16 3x4", 4, 3, dict(dtype=torch.float16), REPS),
+             ("fp16 3x(2x4)", 8, 3, dict(dtype=torch.float16, dcn_couple=4), REPS))
+for name, B, NS, kw, reps in CASES:
     net = PoseNet(PoseNetConfig(), seed=0, use_graph=True, inflight=NS, **kw).cuda()
     d = [{k: torch.from_numpy(v).cuda() for k, v in synth.synth_batch(B, seed=81 + i).items()} for i in range(NS)]
     ref = []
