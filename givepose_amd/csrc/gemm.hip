@@ -1576,17 +1576,21 @@ template <typename T, int WM, int WN, int MT, int NT, int NS, bool DB = false, i
 // a 128 x 128 tile leaves 32 workgroups on 256 CUs, each walking K through a global -> LDS -> register pipeline whose fill and
 // drain ARE the kernel (10 / 15 us per fc1 / fc2 inside a hipGraph chain; split-K adds a reduce launch).  This kernel is built for
 // latency instead:
-//   * workgroup tile (16 MT) x (16 NT) -- 16 x 32 at M <= 512: 1024 workgroups for fc1, 256 for fc2;
-//   * the four waves of a workgroup split K four ways; a wave loads its operand fragments STRAIGHT from global memory in the MFMA
-//     layout (lane (r, q): row r, 8 consecutive k at 8 q of each 32-wide step = one 16-byte load, X and W alike -- both are
-//     K-contiguous), ALL of its K range at once (one wave per SIMD: up to 16 steps x 3 fragments x 4 = 192 registers in flight),
-//     so a wave pays ONE memory round trip, not one per pipeline stage;
-//   * the four partial tiles meet in LDS and are added in FIXED order (wave 0..3: deterministic, replay-bitwise), then bias /
-//     activation / gamma-residual exactly as the tile kernels' lean epilogue (epi_apply) and one 8-byte store per lane;
+//   * workgroup tile (16 MT) x 32, MT in {1, 2, 4} (chosen per launch by the cost model in gp_gemm): e.g. 32 x 32 for fc1 at one crop
+//     (512 workgroups), 16 x 32 for fc2 (256);
+//   * the four waves of a workgroup split K four ways; a wave loads its operand fragments STRAIGHT from global memory -- 16 bytes
+//     per lane, row-major over the lanes (lane l: row l / 4, chunk l % 4 of the 32-wide K step: four lanes read 64 contiguous
+//     bytes; X and W alike, both are K-contiguous) -- ALL of its K range at once (one wave per SIMD: up to 16 steps x 3
+//     fragments x 4 = 192 registers in flight), so a wave pays ONE memory round trip, not one per pipeline stage; a ds_bpermute
+//     per dword then puts each fragment into the MFMA operand layout (to_mfma_lanes below);
+//   * the four partial tiles meet in LDS and are added in FIXED order (wave 0..3: deterministic, replay-bitwise, the same for
+//     every MT), then bias / activation / gamma-residual exactly as the tile kernels' lean epilogue (epi_apply) and one 8-byte
+//     store per lane; optionally the tile kernels' fused GroupNorm statistics (GN: 64-row tiles);
 //   * the epilogue's bias / gamma / residual loads are issued before the K loop (their latency hides under the operand loads).
 // Operand roles as everywhere in this file: W is the MFMA A operand and X the B operand, so a lane ends up with 4 consecutive
-// n of one row m.  3 x 3 / stride 1 / pad 1 convs (the heads' 256 -> 256 convs at 16 x 16 .. 64 x 64) run through the same kernel:
-// a row is an output pixel, a 32-wide K step lies inside one filter tap (Cin % 32 == 0), out-of-image taps load nothing.
+// n of one row m.  Convs (the heads' 3 x 3 256 -> 256 convs, the 2 x 2 down-sampling convs) run through the same kernel:
+// a row is an output pixel, a 32-wide K step lies inside one filter tap (Cin % 32 == 0), out-of-image taps are masked to zero.
+
 // a fragment loaded row-major over the lanes (lane l: row l / 4, chunk l % 4) -> the MFMA operand layout (lane l: row l % 16, chunk l / 16):
 // MFMA lane (r, q) pulls the four dwords of lane 4 r + q through the LDS crossbar (no LDS memory involved)
 __device__ __forceinline__ half8 to_mfma_lanes(half8 v, int pull) {
