@@ -219,6 +219,47 @@ __device__ __forceinline__ void bilerp_v_vec(Vec16<T>& o, float hy, const float*
     }
 }
 
+// GELU for fp16 storage on PACKED fp16 arithmetic (round 5): gelu(x) = max(x, 0) + R(min(|x|, 4)), R(a) = a (Phi(a) - 1) (even in x,
+// -> 0 for large a: every error below is ABSOLUTE, of the size of one fp16 rounding of a value in [0.25, 0.5)), R as a degree-7
+// polynomial in u = a / 2 - 1 (minimax fit, |R error| 1.95e-4 in exact arithmetic; coefficients <= 0.33 in this variable: Horner in
+// fp16 stays well conditioned -- in the variable a the same polynomial has coefficients up to 58 and loses two digits).  13 operations
+// per TWO values (cvt_pk, |x|, min, u, 7 FMAs, max, add) against 2 x 12 + a conversion for gelu_poly2, and the result IS the fp16
+// output.  Why it matters: on a SIMD every VALU instruction costs ~4.5 issue cycles that no MFMA of either resident wave hides
+// (scripts/probes/mfma_valu_coissue.hip, profiles/r05_fc1_cycle_ablation.txt).  scripts/gelu16_fit.py: fit + simulation (rms error for
+// x ~ N(0, 1): 3.0e-4 against 1.4e-4 for the exact GELU rounded to fp16); end to end the fp16 mode's pose errors do not move
+// (profiles/r05_gelu16_end_to_end.txt).  v_pk_fma_f16 is not the packed-fp32 family of DESIGN.md 6b (profiles/r05_repro_pkh.txt).
+// GP_GELU16=0 keeps the fp32 polynomial (A/B switch, read by the launchers).
+constexpr float GELU16_C[8] = {-4.5349121094e-02f, 1.7163085938e-01f, -2.2192382812e-01f, -1.4266967773e-02f,
+                               3.2568359375e-01f, -2.3901367188e-01f, -5.8441162109e-02f, 8.1665039062e-02f};   // c0 .. c7, fp16 values
+__device__ __forceinline__ half2v h2(float v) { return half2v{(half_t)v, (half_t)v}; }
+constexpr int GELU16_SLICES = 13;
+template <int S>
+__device__ __forceinline__ void gelu16_slice(const f32x2& x, half2v& xh, half2v& u, half2v& p) {
+    if constexpr (S == 0) xh = half2v{(half_t)x[0], (half_t)x[1]};
+    else if constexpr (S == 1) u = __builtin_elementwise_max(xh, -xh);
+    else if constexpr (S == 2) u = __builtin_elementwise_min(u, h2(4.0f));
+    else if constexpr (S == 3) u = __builtin_elementwise_fma(u, h2(0.5f), h2(-1.0f));
+    else if constexpr (S == 4) p = __builtin_elementwise_fma(h2(GELU16_C[7]), u, h2(GELU16_C[6]));
+    else if constexpr (S >= 5 && S <= 10) p = __builtin_elementwise_fma(p, u, h2(GELU16_C[10 - S]));
+    else if constexpr (S == 11) xh = __builtin_elementwise_max(xh, h2(0.0f));
+    else if constexpr (S == 12) p = xh + p;
+}
+// NC value pairs walked in lock step (NC independent chains); out[i] = the two fp16 results of x[i], packed
+template <int NC>
+__device__ __forceinline__ void gelu16_xn(const f32x2* x, unsigned* out) {
+    half2v xh[NC], u[NC], p[NC];
+    static_for<0, GELU16_SLICES>([&](auto sc) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) gelu16_slice<decltype(sc)::value>(x[i], xh[i], u[i], p[i]);
+    });
+#pragma unroll
+    for (int i = 0; i < NC; ++i) out[i] = __builtin_bit_cast(unsigned, p[i]);
+}
+static inline bool gp_gelu16_enabled() {   // host side
+    static const bool on = [] { const char* e = getenv("GP_GELU16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 __device__ __forceinline__ float gelu_poly1(float x) { return gelu_poly2(f32x2{x, x})[0]; }
 
 template <typename T> __device__ __forceinline__ float gelu_for(float v) {

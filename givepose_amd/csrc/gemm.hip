@@ -57,6 +57,21 @@ struct GemmKP {
     int ldc16;
 };
 
+// Investigation build only (GP_EXTRA_HIPCC_FLAGS=-DGP_CLOCK_STAMPS GP_BUILD_TAG=clk, scripts/kernel_clock.py): thread 0 of every workgroup
+// stores (s_memtime, s_memrealtime) around the kernel's main loop into the workspace, which nothing else reads in these launches
+// (no split-K): in-kernel shader clock = d memtime / d memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ __forceinline__ void clk_stamp(const GemmKP& p, int which) {
+#ifdef GP_CLOCK_STAMPS
+    if (threadIdx.x == 0 && p.ws && p.splitk <= 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.ws) + ((long)blockIdx.x * 2 + which) * 2;
+        o[0] = t; o[1] = r;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ void epi_store(const GemmKP& p, int m, int n, f32x4 v) {
     if (p.bias) {
@@ -697,18 +712,22 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         // never stored), so no zero page and no per-lane select is needed.
         const bool sdma = !p.conv && (long)BM * p.ldx * sizeof(T) < (1l << 31) && (long)BN * p.K * sizeof(T) < (1l << 31);
         unsigned xo[XI], wo[WI];
+        // TIMING HACK (round 5 probe): dbg 6 = W addressed as K-blocked [N/16][K/32][16][32], dbg 7 = X too (wrong results)
+        const bool kbw = p.dbg == 6 || p.dbg == 7, kbx = p.dbg == 7;
+        const long kblk = p.K / 32;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int r = min((i * NW + wave) * RPI + lrow, p.M - 1 - m0);
-            xo[i] = (unsigned)(((long)r * p.ldx + lchunk * EPT) * sizeof(T));
+            xo[i] = kbx ? (unsigned)((long)(i * NW + wave) * kblk * 1024 + lrow * 64 + lchunk * 16) : (unsigned)(((long)r * p.ldx + lchunk * EPT) * sizeof(T));
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int r = min((i * NW + wave) * RPI + lrow, p.N - 1 - n0);
-            wo[i] = (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
+            wo[i] = kbw ? (unsigned)((long)(i * NW + wave) * kblk * 1024 + lrow * 64 + lchunk * 16) : (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
         }
-        const char* xtile = reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
-        const char* wtile = reinterpret_cast<const char*>(W + (long)n0 * p.K);
+        const char* xtile = kbx ? reinterpret_cast<const char*>(X) + (long)(m0 / 16) * kblk * 1024 : reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
+        const char* wtile = kbw ? reinterpret_cast<const char*>(W) + (long)(n0 / 16) * kblk * 1024 : reinterpret_cast<const char*>(W + (long)n0 * p.K);
+        const long xstep = kbx ? 1024 : RB, wstep = kbw ? 1024 : RB;
         auto stage_s = [&](int buf, int kt) {
             const unsigned xs = lds0 + buf * STAGE + wave * 1024;
             const unsigned ws = xs + BM * RB;
@@ -719,8 +738,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 xadd = seg == 1 ? p.xplane_b : 0;
                 wadd = seg == 0 ? p.wplane_b : 0;
             }
-            const char* bx = xtile + (long)kt * RB + xadd;
-            const char* bw = wtile + (long)kt * RB + wadd;
+            const char* bx = xtile + (long)kt * xstep + xadd;
+            const char* bw = wtile + (long)kt * wstep + wadd;
 #pragma unroll
             for (int i = 0; i < XI; ++i) glds16_s(bx, xo[i], xs + i * NW * 1024);
 #pragma unroll
@@ -742,6 +761,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         __builtin_amdgcn_s_barrier();
         if (grp) __builtin_amdgcn_s_barrier();
         int buf = 0, nbuf = LEAD;
+        clk_stamp(p, 0);
         for (int kt = 0; kt < p.nkt; ++kt) {
             if (p.dbg != 2) {
                 const char* xs = smem + buf * STAGE + xfo;
@@ -776,6 +796,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             buf = buf + 1 == NS ? 0 : buf + 1;
             nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
         }
+        clk_stamp(p, 1);
         if (!grp) __builtin_amdgcn_s_barrier();
     } else
     if constexpr (DB && NS == 2) {
@@ -966,8 +987,10 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     const int lrow = lane >> 2;
     const int wchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
     unsigned woff[WPI];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
+    const bool kbw = p.dbg == 6 || p.dbg == 5, kbx = p.dbg == 5;   // TIMING HACK (round 5 probe, wrong results): K-blocked W / channel-planar X addressing
 #pragma unroll
-    for (int i = 0; i < WPI; ++i) woff[i] = (unsigned)(((n0 + (i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
+    for (int i = 0; i < WPI; ++i) woff[i] = kbw ? (unsigned)(((n0 / 16 + i * 8 + wave) * (p.K / 32)) * 1024 + lrow * 64 + wchunk * 16)
+                                                : (unsigned)(((n0 + (i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3.  32-bit byte offsets from the
     // image base (scalar); halo / border lanes point at the zero page instead (xvalid)
     unsigned xoff[XJ];
@@ -981,7 +1004,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         const int gy = h0 - 1 + wy, gx = wx - 1;
         const int lc = (lane & 3) ^ (((px >> 2) & 1) << 1);
         const bool ok = i < NI && px < NP && wx < WIMG + 2 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)WIMG;
-        xoff[j] = ok ? (unsigned)(((gy * WIMG + gx) * Cin + lc * 8) * 2) : 0u;
+        xoff[j] = !ok ? 0u : kbx ? (unsigned)((gy * WIMG + gx) * 64 + lc * 16) : (unsigned)(((gy * WIMG + gx) * Cin + lc * 8) * 2);
         if (ok) xvalid |= 1u << j;
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
@@ -989,7 +1012,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         int cc = g;
         long plane = 0;
         if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 0 ? p.wplane_b : 0; }
-        const char* base = reinterpret_cast<const char*>(W) + plane + (tap * Cin + cc * 32) * 2;
+        const char* base = reinterpret_cast<const char*>(W) + plane + (kbw ? (tap * (Cin >> 5) + cc) * 1024 : (tap * Cin + cc * 32) * 2);
         const unsigned d = lds0 + buf * WST + wave * 1024;
         glds16_s(base, woff[0], d);
         if constexpr (WPI == 2) glds16_s(base, woff[WPI - 1], d + 8192);
@@ -999,7 +1022,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         long plane = 0;
         if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 1 ? p.xplane_b : 0; }
         const unsigned d = lds0 + WIN0 + (g & 1) * WINB + (wave + 8 * j) * 1024;
-        const char* src = ximg + plane + xoff[j] + cc * 64;
+        const char* src = ximg + plane + xoff[j] + (kbx ? cc * (p.H * WIMG * 64) : cc * 64);
         glds16((xvalid >> j) & 1 ? src : zp, d);
     };
 
@@ -1045,6 +1068,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     if (grp) __builtin_amdgcn_s_barrier();
 
     uint4 xf[MT], wf[NT];
+    clk_stamp(p, 0);
     int st = 0, rbuf = 0, wbuf = LEAD, ops1 = WPI, ops2 = WPI;   // DMA ops issued one / two phases ago (W of steps 1..LEAD-1 at first)
     for (int cc = 0; cc < NG; ++cc) {      // (cc = global chunk index; SPL: segment cc / NCC)
         if constexpr (SPL) {
@@ -1119,6 +1143,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xa[mt] += (cc & 1) ? -WINB : WINB;     // the other window buffer
     }
+    clk_stamp(p, 1);
     if (!grp) __builtin_amdgcn_s_barrier();
 
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
@@ -1536,6 +1561,7 @@ __global__ __launch_bounds__(512) void gemm_wreg2_kernel(const GemmKP p) {
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b4[nt];
     __builtin_amdgcn_s_barrier();         // tiles 0 and 1 are published
 
+    clk_stamp(p, 0);
     tile(0, std::false_type{});
     take();
     sync(0);
@@ -1547,7 +1573,263 @@ __global__ __launch_bounds__(512) void gemm_wreg2_kernel(const GemmKP p) {
         take();
         sync(t);
     }
+    clk_stamp(p, 1);
     activate();
+    stores(T - 1);
+}
+
+// =====================================================================================================
+// Weights-in-registers GEMM, third form (variant 19, round 5): gemm_wreg2_kernel on v_mfma_f32_32x32x16_f16.
+// Why: the kernel is bound by the SIMD's vector ISSUE, not by its matrix pipe (header of gemm_wreg_kernel): an MFMA
+// holds the issue port for 8 cycles whatever its shape, and a 32x32x16 MFMA does in 32 pipe cycles what two 16x16x32 MFMAs do in
+// 2 x 16 -- half the MFMA issue slots per FLOP (per tile and wave 32 x 8 = 256 cycles instead of 64 x 8 = 512), the same fragment
+// reads (one ds_read_b128 per K step of 16 instead of two per K step of 32) and the same registers (a wave's 32 W rows x 512 K are
+// 32 A fragments = 128 VGPRs either way; 16 accumulators).  The GELU of the previous tile rides behind the MFMAs as before, six
+// plain fp32 operations behind each (G16 = 0: the polynomial of gelu_poly2, same roundings), or -- G16 = 1 -- as 13 PACKED fp16
+// operations per two values (gelu16_* below: v_pk_fma_f16 is not the packed-fp32 family of DESIGN.md 6b).
+// Layouts: A fragment ks: lane l = W row perm(l % 32), k = 16 ks + 8 (l / 32) .. + 8; B fragment ks: pixel row l % 32 of the X tile,
+// the same k.  Accumulator register r of lane l is A row 8 (r / 4) + 4 (l / 32) + r % 4, pixel l % 32; perm maps A row 8 g + 4 h + e
+// to channel 16 (g / 2) + 8 h + 4 (g % 2) + e, so that a lane's registers 8 s .. 8 s + 7 are the 8 consecutive channels
+// 16 s + 8 h .. + 8: two 16-byte stores per lane and tile, each instruction writing 32 rows x 32 contiguous bytes.
+// LDS ring, hazards, vmcnt accounting: as gemm_wreg2_kernel (4 DMA pieces and 2 stores per tile and wave).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// S32 = 1: v_mfma_f32_32x32x16_f16 (layouts in the header above); S32 = 0: v_mfma_f32_16x16x32_f16 with gemm_wreg2_kernel's layouts (the chip holds a
+// ~10 % higher clock on that shape: scripts/kernel_clock.py).  Both: TWO accumulator sets -- tile t accumulates into set t & 1, its first
+// MFMA per accumulator takes the bias registers as the C operand, and the activation of tile t - 1 reads set (t - 1) & 1 in place: the 32
+// v_mov per tile and wave of gemm_wreg2_kernel's take() are gone (on this SIMD every VALU instruction adds ~4.5 issue cycles to the
+// tile, two waves or one: scripts/probes/mfma_valu_coissue.hip).
+template <int EPI, int S32, int G16>
+__global__ __launch_bounds__(512) void gemm_wreg3_kernel(const GemmKP p) {
+    constexpr int K = 512, KS = S32 ? K / 16 : K / 32, TM = 32, NBUF = 4, BUFB = TM * K * 2, NMF = S32 ? KS : 4 * KS;
+    constexpr bool GELU = EPI == GP_EPI_GELU, H16 = GELU && G16;
+    __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUFB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5, fr = lane & 15, fq = lane >> 4;
+    const int nsl = p.N >> 8;
+    const int bid = blockIdx.x;
+    const int item = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // XCD-contiguous chunks of the (m group, n slice) list (host: gridDim.x % 8 == 0)
+    const int mg = item / nsl, ns = item - mg * nsl;
+    const long m0 = (long)mg * p.tiles_m * TM;
+    const int T = min(p.tiles_m, (int)((p.M - m0) / TM));
+    if (T <= 0) return;
+    const int nb = ns * 256 + wave * 32;
+
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    const char* xsrc = reinterpret_cast<const char*>(p.X) + ((m0 + wave * 4) * (long)p.ldx) * 2;
+    const long rowb = (long)p.ldx * 2;
+    unsigned xoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xoff[i] = (unsigned)(i * rowb) + ((lane ^ ((wave * 4 + i) & 15)) << 4);
+    auto piece = [&](int t, int i) {          // piece i (one row of 1 KB, chunk-swizzled on the source side) of this wave's four rows of tile t
+        glds16_s(xsrc + (long)t * TM * rowb, xoff[i], lds0 + (t & (NBUF - 1)) * BUFB + (wave * 4 + i) * 1024);
+    };
+    // B fragments.  S32: K step ks (16 wide): row j, logical 16-byte chunk 2 ks + h, stored at chunk ^ (j & 15):
+    //   byte j * 1024 + (ks / 8) * 256 + (((2 (ks % 8) + h) ^ (j & 15)) << 4).
+    // 16x16x32: fragment (mt, ks): row mt * 16 + fr, chunk (4 ks + fq) ^ fr: byte fr * 1024 + mt * 16384 + (ks / 4) * 256 + (((4 (ks % 4)) ^ (fq ^ fr)) << 4)
+    constexpr int NBO = S32 ? 8 : 4;
+    unsigned boff[NBO];
+#pragma unroll
+    for (int q = 0; q < NBO; ++q) boff[q] = S32 ? j * 1024 + ((((2 * q) | h) ^ (j & 15)) << 4) : fr * 1024 + (((q * 4) ^ (fq ^ fr)) << 4);
+
+    uint4 wf[S32 ? KS : 2 * KS];      // S32: [ks]; 16x16x32: [nt * KS + ks]
+    f32x16 acc[2], b16;               // 16x16x32: registers 4 (nt * 2 + mt) .. + 4 of a set = accumulator (nt, mt); b16[4 nt .. + 4] = bias of n-tile nt
+    unsigned o16[8];                  // G16: the packed fp16 results of the previous tile
+    f32x2 v[8];                       // fp32 activations: the values of the previous tile, activated in place
+    // value pair c of a set (two consecutive channels of one row) and where it goes:
+    //   S32:      registers 2 c, 2 c + 1: row j, channels nb + 16 (c / 4) + 8 h + 2 (c % 4)       -> store s = c / 4, dword c % 4
+    //   16x16x32: c = mt * 4 + nt * 2 + e: registers 4 (nt * 2 + mt) + 2 e, + 1: row mt * 16 + fr, channels nb + 8 fq + 4 nt + 2 e -> store mt, dword nt * 2 + e
+    auto pair_reg = [](int c) constexpr { return S32 ? 2 * c : 4 * (((c >> 1) & 1) * 2 + (c >> 2)) + 2 * (c & 1); };
+    half_t* Cw = reinterpret_cast<half_t*>(p.C) + (S32 ? (m0 + j) * (long)p.ldc + nb + h * 8 : (m0 + fr) * (long)p.ldc + nb + fq * 8);
+    f32x2 gx[2], gt[2], gp[2];
+    half2v hx[2], hu[2], hp[2];
+    float c1v = GELU_H[1];
+    asm volatile("" : "+v"(c1v));
+
+    auto allowed = [&](int t) { return (t >= 2 ? 2 : 0) + (t + 2 < T ? 4 : 0) + (t >= 1 ? 2 : 0); };
+    auto sync = [&](int t) {       // RAW wait for the own pieces of tile t+1, then the tile's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= 2 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // steady state: 2 + 4 + 2
+        else wait_vmcnt_n(allowed(t));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stores = [&](int t) {   // 2 stores of 16 bytes per lane, one instruction each
+        half_t* c = Cw + (long)t * TM * p.ldc;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            pf_u32x4 ov;
+            if constexpr (H16) {
+                ov = pf_u32x4{o16[s2 * 4], o16[s2 * 4 + 1], o16[s2 * 4 + 2], o16[s2 * 4 + 3]};
+            } else {
+                const f32x2 a = v[s2 * 4], b = v[s2 * 4 + 1], cc = v[s2 * 4 + 2], d = v[s2 * 4 + 3];
+                const half8 o = {(half_t)a[0], (half_t)a[1], (half_t)b[0], (half_t)b[1], (half_t)cc[0], (half_t)cc[1], (half_t)d[0], (half_t)d[1]};
+                ov = __builtin_bit_cast(pf_u32x4, o);
+            }
+            const half_t* dst = S32 ? c + s2 * 16 : c + (long)s2 * 16 * p.ldc;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+        }
+    };
+    // activation of accumulator set `par` outside the MFMA shadow (the last tile; the cheap activations): -> v / o16
+    auto activate = [&](auto parc) {
+        constexpr int par = decltype(parc)::value;
+        static_for<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value, r = pair_reg(c);
+            v[c] = f32x2{acc[par][r], acc[par][r + 1]};
+        });
+        if constexpr (H16) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                half2v xh, u, pp;
+                static_for<0, GELU16_SLICES>([&](auto sc) { gelu16_slice<decltype(sc)::value>(v[c], xh, u, pp); });
+                o16[c] = __builtin_bit_cast(unsigned, pp);
+            }
+        } else if constexpr (GELU) {
+            gelu_poly2_xn<4>(v);
+            gelu_poly2_xn<4>(v + 4);
+        } else if constexpr (EPI == GP_EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{fmaxf(v[i][0], 0.0f), fmaxf(v[i][1], 0.0f)};
+        } else if constexpr (EPI == GP_EPI_LRELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = f32x2{v[i][0] > 0.0f ? v[i][0] : 0.1f * v[i][0], v[i][1] > 0.0f ? v[i][1] : 0.1f * v[i][1]};
+        }
+    };
+    // one tile into accumulator set PAR, with the GELU of set PAR ^ 1 (the previous tile) in the shadow of its MFMAs: the 8 value pairs go
+    // through the polynomial two chains at a time (call n of the tile = pair group n / (2 NSL), slice (n % (2 NSL)) / 2, chain n % 2), the
+    // calls spread evenly over the NMF MFMAs (fp32: 96 calls of two operations; packed fp16: 104 calls of one).  B fragments are read two
+    // K steps ahead, one DMA piece of tile t+2 in each quarter of the tile.
+    auto tile = [&](int t, auto parc, auto shadow) {
+        constexpr int PAR = decltype(parc)::value;
+        constexpr bool SH = decltype(shadow)::value && GELU;
+        constexpr int NSL = H16 ? GELU16_SLICES : GELU_SLICES, NCALL = 8 * NSL;
+        const char* xb = smem + (t & (NBUF - 1)) * BUFB;
+        auto shadow_calls = [&](auto ic) {      // the calls that ride behind MFMA i of the tile
+            if constexpr (SH) {
+                constexpr int i = decltype(ic)::value, n0 = i * NCALL / NMF, n1 = (i + 1) * NCALL / NMF;
+                static_for<n0, n1>([&](auto nc) {
+                    constexpr int n = decltype(nc)::value, g = n / (2 * NSL), m = n % (2 * NSL), slot = m / 2, ch = m % 2, c = 2 * g + ch, r = pair_reg(c);
+                    if constexpr (H16) {
+                        if constexpr (slot == 0) hx[ch] = half2v{(half_t)acc[PAR ^ 1][r], (half_t)acc[PAR ^ 1][r + 1]};
+                        else gelu16_slice<slot>(v[0], hx[ch], hu[ch], hp[ch]);
+                        if constexpr (slot == GELU16_SLICES - 1) o16[c] = __builtin_bit_cast(unsigned, hp[ch]);
+                    } else {
+                        if constexpr (slot == 0) v[c] = f32x2{acc[PAR ^ 1][r], acc[PAR ^ 1][r + 1]};
+                        gelu_poly2_slice<slot>(v[c], gx[ch], gt[ch], gp[ch], c1v);
+                    }
+                });
+            }
+        };
+        if constexpr (S32) {
+            uint4 bf[3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf[ks] = *reinterpret_cast<const uint4*>(xb + boff[ks & 7] + (ks >> 3) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, KS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                if constexpr (ks + 2 < KS) bf[(ks + 2) % 3] = *reinterpret_cast<const uint4*>(xb + boff[(ks + 2) & 7] + ((ks + 2) >> 3) * 256);
+                if constexpr (ks % 8 == 4) {
+                    if (t + 2 < T) piece(t + 2, ks / 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ks == 0) acc[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&wf[ks]), *reinterpret_cast<const half8*>(&bf[ks % 3]), b16, 0, 0, 0);
+                else acc[PAR] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&wf[ks]), *reinterpret_cast<const half8*>(&bf[ks % 3]), acc[PAR], 0, 0, 0);
+                shadow_calls(std::integral_constant<int, ks>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            uint4 bf[3][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) bf[ks][mt] = *reinterpret_cast<const uint4*>(xb + boff[ks & 3] + mt * 16 * 1024 + (ks >> 2) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, KS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                if constexpr (ks + 2 < KS) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        bf[(ks + 2) % 3][mt] = *reinterpret_cast<const uint4*>(xb + boff[(ks + 2) & 3] + mt * 16 * 1024 + ((ks + 2) >> 2) * 256);
+                }
+                if constexpr (ks % 4 == 2) {
+                    if (t + 2 < T) piece(t + 2, ks / 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int q = decltype(jc)::value, nt = q / 2, mt = q % 2, r0 = 4 * q;
+                    f32x4 cin;
+                    if constexpr (ks == 0) cin = f32x4{b16[4 * nt], b16[4 * nt + 1], b16[4 * nt + 2], b16[4 * nt + 3]};
+                    else cin = f32x4{acc[PAR][r0], acc[PAR][r0 + 1], acc[PAR][r0 + 2], acc[PAR][r0 + 3]};
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&wf[nt * KS + ks]), *reinterpret_cast<const half8*>(&bf[ks % 3][mt]), cin, 0, 0, 0);
+                    acc[PAR][r0] = d[0]; acc[PAR][r0 + 1] = d[1]; acc[PAR][r0 + 2] = d[2]; acc[PAR][r0 + 3] = d[3];
+                    shadow_calls(std::integral_constant<int, ks * 4 + q>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        }
+    };
+
+    // ---- prologue: tiles 0 and 1, the resident W fragments, the bias
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        if (t < T)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece(t, i);
+    const PfSink pfs = prefetch_issue(p, bid, gridDim.x, wave, 8, lane);
+    if constexpr (S32) {
+        // lane (j, h) of fragment ks holds W[nb + perm(j)][ks * 16 + h * 8 .. + 8], perm(8 g + 4 hh + e) = 16 (g / 2) + 8 hh + 4 (g % 2) + e
+        const int pj = 16 * (j >> 4) + 8 * ((j >> 2) & 1) + 4 * ((j >> 3) & 1) + (j & 3);
+        const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + pj) * K + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(Wp + ks * 16);
+        // accumulator register r = channel 16 (r / 8) + 8 h + r % 8
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = p.bias ? p.bias[nb + 16 * (r >> 3) + 8 * h + (r & 7)] : 0.0f;
+    } else {
+        // lane (fr, fq) of fragment (nt, ks) holds W[nb + 8 (fr / 4) + 4 nt + fr % 4][ks * 32 + fq * 8 .. + 8]
+        const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + (fr >> 2) * 8 + (fr & 3)) * K + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf[nt * KS + ks] = *reinterpret_cast<const uint4*>(Wp + (long)nt * 4 * K + ks * 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = (p.bias && r < 8) ? p.bias[nb + fq * 8 + r] : 0.0f;   // registers 4 nt .. + 4: channels nb + 8 fq + 4 nt .. + 4
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc does not wait for the W loads inside the loop
+    prefetch_retire(pfs);
+    __builtin_amdgcn_s_barrier();         // tiles 0 and 1 are published
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    clk_stamp(p, 0);
+    tile(0, P0{}, std::false_type{});
+    sync(0);
+    int t = 1;
+    for (; t + 1 < T; t += 2) {
+        tile(t, P1{}, std::true_type{});
+        if constexpr (!GELU) activate(P0{});
+        __builtin_amdgcn_sched_barrier(0);
+        stores(t - 1);
+        sync(t);
+        tile(t + 1, P0{}, std::true_type{});
+        if constexpr (!GELU) activate(P1{});
+        __builtin_amdgcn_sched_barrier(0);
+        stores(t);
+        sync(t + 1);
+    }
+    if (t < T) {          // T even: one more tile into set 1
+        tile(t, P1{}, std::true_type{});
+        if constexpr (!GELU) activate(P0{});
+        __builtin_amdgcn_sched_barrier(0);
+        stores(t - 1);
+        sync(t);
+        clk_stamp(p, 1);
+        activate(P1{});
+    } else {
+        clk_stamp(p, 1);
+        activate(P0{});
+    }
     stores(T - 1);
 }
 
@@ -1831,6 +2113,12 @@ static bool wreg_enabled() {
     return on;
 }
 
+static int wreg_variant() {   // GP_GEMM_WREG_VARIANT=17|19|20|21|22: which weights-in-registers kernel the automatic choice takes (A/B switch; default 21,
+                              // and 22 -- the same kernel with the activation in fp32 -- for the epilogues other than GELU)
+    static const int v = [] { const char* e = getenv("GP_GEMM_WREG_VARIANT"); const int x = e ? atoi(e) : (gp_gelu16_enabled() ? 21 : 22); return (x >= 19 && x <= 22) ? x : 17; }();
+    return v;
+}
+
 static long co_min_tiles() {   // fewest 256 x 256 tiles that still go to the ping-pong kernel when batches overlap (GP_GEMM_CO_MIN_TILES: A/B)
     static const long k = [] { const char* e = getenv("GP_GEMM_CO_MIN_TILES"); return e ? atol(e) : 32l; }();
     return k;
@@ -1995,7 +2283,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // against; measured, scripts/split_variants.py: it wins from ~140 tiles of 256 x 256 up, below that the 128 x 128
             // two-workgroups-per-CU tile does; the 256 x 128 tile never)
             if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
-            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = (d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0) ? 17 : 16;
+            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = (d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0) ? (wreg_variant() == 20 && d->epilogue != GP_EPI_GELU ? 19 : wreg_variant() == 21 && d->epilogue != GP_EPI_GELU ? 22 : wreg_variant()) : 16;
             else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= co_min_tiles()) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }
@@ -2009,7 +2297,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (!d->out_f32 || split) && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 && !d->out_planes &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
-    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || (variant >= 16 && variant <= 18)) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
+    GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || (variant >= 16 && variant <= 22)) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
     // c16 is written by the generic epilogue of gemm_big_kernel only (out_f32 keeps every tile off the lean one); the window conv
@@ -2066,6 +2354,28 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             case GP_EPI_LRELU: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_LRELU>, dim3(grid), dim3(512), 0, s, p); break;
             default: hipLaunchKernelGGL(gemm_wreg2_kernel<GP_EPI_NONE>, dim3(grid), dim3(512), 0, s, p); break;
         }
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
+    if (variant >= 19 && variant <= 22) {   // weights in registers, two accumulator sets: 19 / 20 on 32x32x16 MFMAs, 22 / 21 on 16x16x32; 20 / 21: GELU on packed fp16
+        GP_REQUIRE(wreg_ok && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0, "gp_gemm: variant 19-22 needs a plain fp16 GEMM with K = 512, N %% 256 == 0, M %% 32 == 0, ldc %% 8 == 0, "
+                   "16-byte aligned C, epilogue none/gelu/relu/lrelu");
+        const int nsl = d->N / 256, tiles = d->M / 32;
+        const int want = gp_num_cus() / nsl > 0 ? gp_num_cus() / nsl : 1;
+        p.tiles_m = cdiv(tiles, want);
+        const int groups = cdiv(tiles, p.tiles_m);
+        const int grid = cdiv(groups * nsl, 8) * 8;
+        const bool s32 = variant <= 20, g16 = variant == 20 || variant == 21;
+#define GP_W3(E, S, G) hipLaunchKernelGGL((gemm_wreg3_kernel<E, S, G>), dim3(grid), dim3(512), 0, s, p)
+        switch (d->epilogue) {
+            case GP_EPI_GELU:
+                if (s32) { if (g16) GP_W3(GP_EPI_GELU, 1, 1); else GP_W3(GP_EPI_GELU, 1, 0); }
+                else { if (g16) GP_W3(GP_EPI_GELU, 0, 1); else GP_W3(GP_EPI_GELU, 0, 0); }
+                break;
+            case GP_EPI_RELU: if (s32) GP_W3(GP_EPI_RELU, 1, 0); else GP_W3(GP_EPI_RELU, 0, 0); break;
+            case GP_EPI_LRELU: if (s32) GP_W3(GP_EPI_LRELU, 1, 0); else GP_W3(GP_EPI_LRELU, 0, 0); break;
+            default: if (s32) GP_W3(GP_EPI_NONE, 1, 0); else GP_W3(GP_EPI_NONE, 0, 0); break;
+        }
+#undef GP_W3
         GP_LAUNCH_CHECK("gp_gemm");
     }
     if (variant == 13) {

@@ -49,7 +49,7 @@ __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 acc
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
 }
 
-template <int C>
+template <int C, int G16>     // G16: GELU on packed fp16 (common.hpp gelu16_slice), the default; 0: the fp32 polynomial (GP_GELU16=0)
 __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
     constexpr int HD = 4 * C, NCH = HD / 32, KS = C / 32, CT = C / 16, MT = 2;
     constexpr int ROWB = C * 2;                        // bytes per W1 row
@@ -173,6 +173,23 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
                 v[(mt * 2 + nt) * 2 + 0] = f32x2{acc1[nt][mt][0], acc1[nt][mt][1]};
                 v[(mt * 2 + nt) * 2 + 1] = f32x2{acc1[nt][mt][2], acc1[nt][mt][3]};
             }
+        uint4 hb[MT];
+        if constexpr (G16) {
+            // packed fp16: 13 operations per value PAIR, and the packed results are the dwords of GEMM2's B fragments as they stand
+            unsigned hw[8];
+            if (p.dbg == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hw[i] = __builtin_bit_cast(unsigned, half2v{(half_t)v[i][0], (half_t)v[i][1]});
+            } else if constexpr (C == 128) {
+                gelu16_xn<8>(v, hw);
+            } else {   // C = 256: four chains at a time (register budget)
+                gelu16_xn<4>(v, hw);
+                asm volatile("" : "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(hw[0]), "v"(hw[1]), "v"(hw[2]), "v"(hw[3]));
+                gelu16_xn<4>(v + 4, hw + 4);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) hb[mt] = uint4{hw[mt * 4], hw[mt * 4 + 1], hw[mt * 4 + 2], hw[mt * 4 + 3]};
+        } else {
         if (p.dbg == 1) {
         } else if constexpr (C == 128) {
             gelu_poly2_x8(v);
@@ -184,7 +201,6 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
                 if (i + 2 < 8) asm volatile("" : "+v"(v[i + 2]), "+v"(v[i + 3]) : "v"(v[i]), "v"(v[i + 1]));
             }
         }
-        uint4 hb[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             half8 h;
@@ -194,6 +210,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
                 h[e * 2 + 1] = (half_t)v[mt * 4 + e][1];
             }
             hb[mt] = *reinterpret_cast<const uint4*>(&h);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- GEMM2: out[32 rows][C] += h_chunk * W2p_chunk^T
@@ -292,7 +309,13 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
     const double bytes = 3.0 * M * C * 2 + 2.0 * 4 * C * C * 2;
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
     gp_timing_label("convnext_mlp C%d M%ld", C, M);
-    if (C == 128) hipLaunchKernelGGL(convnext_mlp_kernel<128>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(convnext_mlp_kernel<256>, dim3((unsigned)(M / 256)), dim3(512), 0, s, p);
+    const dim3 grid((unsigned)(M / 256));
+    if (gp_gelu16_enabled()) {
+        if (C == 128) hipLaunchKernelGGL((convnext_mlp_kernel<128, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((convnext_mlp_kernel<256, 1>), grid, dim3(512), 0, s, p);
+    } else {
+        if (C == 128) hipLaunchKernelGGL((convnext_mlp_kernel<128, 0>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((convnext_mlp_kernel<256, 0>), grid, dim3(512), 0, s, p);
+    }
     GP_LAUNCH_CHECK("gp_convnext_mlp");
 }

@@ -146,7 +146,17 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ xyz4, co
         half8 o;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-#ifdef NOPK
+#if defined(PKH)
+            // round 5: is the PACKED FP16 family (v_pk_fma_f16, which the fp16 GELU of the GEMM kernels now uses) disturbed like v_pk_fma_f32?
+            // Two channels per instruction, operands rounded to fp16 first; compared bitwise with the same arithmetic run solo.
+            if (e & 1) continue;
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 t = {(half_t)bv[e], (half_t)bv[e + 1]};
+            t = __builtin_elementwise_fma(h2{(half_t)w2[e], (half_t)w2[e + 1]}, h2{(half_t)p[2], (half_t)p[2]}, t);
+            t = __builtin_elementwise_fma(h2{(half_t)w1[e], (half_t)w1[e + 1]}, h2{(half_t)p[1], (half_t)p[1]}, t);
+            t = __builtin_elementwise_fma(h2{(half_t)w0[e], (half_t)w0[e + 1]}, h2{(half_t)p[0], (half_t)p[0]}, t);
+            o[e] = t[0]; o[e + 1] = t[1];
+#elif defined(NOPK)
             float t = bv[e];
             asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w2[e]), "v"(p[2]));
             asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(w1[e]), "v"(p[1]));
