@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--h2d", default=None, choices=["crops", "frames"],
                     help="put the host -> HBM transfer of every step's inputs INSIDE the timed step (pipelined on a copy stream); "
                          "the line then says so in config.inputs and is not the metric's `value` (inputs resident)")
+    ap.add_argument("--repeat", type=int, default=0, help="timed regions of K steps each (value = their median); 0 = 5 when K < 100, else 1")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="profiling runs only: skip the overlap / grouping self-check (its extra forwards would be counted)")
     ap.add_argument("--no-serial", action="store_true", help="profiling runs only: skip the serial legs")
@@ -252,16 +253,31 @@ def main():
         for _ in range(3):
             run_single.step()
     calls = [run.step] * n_launch + ([run_single.step] * n_single if run_single is not None else [])
-    it = iter(calls)
-    dt = timed(lambda: next(it)(), len(calls), fence, world, dev)
+    # The timed region is EXACTLY K steps, fenced on both sides.  With K < 100 it lasts ~0.1 s: it is then repeated (5 regions, each K
+    # steps, each fenced) and `value` is the MEDIAN region, `value_min` / `value_max` the spread -- one region of 10 launches has no
+    # noise estimate (round-4 review).  `steps` stays K.
+    n_regions = max(1, args.repeat if args.repeat > 0 else (5 if args.steps < 100 else 1))
+    dts = []
+    for _ in range(n_regions):
+        it = iter(calls)
+        dts.append(timed(lambda: next(it)(), len(calls), fence, world, dev))
+    dt = statistics.median(dts)
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    # RCCL really saw `world` ranks: the all-reduced sum of ones (1 without a communicator)
+    n_ranks_seen = 1
+    if coll:
+        tt = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(tt)
     peak = PEAK_F16_TFLOPS if args.dtype != "f32" else PEAK_F32_TFLOPS
 
     line = {
         "metric": "images/sec PoseNet fwd, bs=64 256x256 fp16, 1/2/4/8 MI355X; % MFMA roofline",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "timed_regions": n_regions, "value_min": round(world * B * args.steps / max(dts), 2), "value_max": round(world * B * args.steps / min(dts), 2),
+        "n_ranks_seen": n_ranks_seen,
         "dtype": {"f16": "f16", "f32": "f32", "split": "f16x2 split operands (fp32 storage / accumulate)"}[args.dtype], "data": "synthetic",
         "config": {"workload": ("PoseNet.forward: " + ("ResNet-34" if args.workload.startswith("resnet34") else "ConvNeXt-B")
                                 + " trunk + SizeHead + NOCS TopDownXyzHead + "
@@ -309,7 +325,7 @@ def main():
             from givepose_amd.rot_cond import rot_error_bound
             alone = PoseNet(cfg, seed=0, use_graph=False, inflight=1, **mode).to(dev)
             dmax, bit = torch.zeros(4), True
-            logit_rel, explained, worst_ratio, allo_median = 0.0, True, 0.0, 0.0
+            logit_rel, explained, worst_ratio, allo_median, n_excused, ego_p90 = 0.0, True, 0.0, 0.0, 0, 0.0
             for j in range(G):
                 d1 = {k: torch.from_numpy(v).to(dev) for k, v in singles[j].items()}
                 o = alone.forward_device(d1, dev)
@@ -328,7 +344,9 @@ def main():
                 a6 = o["rot6d"].float().cpu()
                 gj = g6[j * B:(j + 1) * B]
                 logit_rel = max(logit_rel, float((gj - a6).abs().max() / a6.abs().max()))
-                bnd = rot_error_bound(a6, gj)
+                bnd = rot_error_bound(a6, gj, max_logit_err=1.5e-2 * float(a6.abs().max()))   # inf only where the separate forward's logits alone excuse the crop
+                n_excused += int(torch.isinf(bnd).sum())
+                ego_p90 = max(ego_p90, float(per[min(per.numel() - 1, int(0.9 * per.numel()))]))
                 d_allo = (gallo[j * B:(j + 1) * B] - o["rot_allo"].float().cpu().reshape(-1, 9)).abs().max(1).values
                 allo_median = max(allo_median, float(d_allo.sort().values[d_allo.numel() // 2]))
                 ratio = d_allo.double() / bnd
@@ -345,13 +363,20 @@ def main():
             grouped_vs_alone["rot_allo_median_over_crops"] = allo_median
             grouped_vs_alone["every_crop_allocentric_dR_explained_by_its_conditioning"] = explained
             grouped_vs_alone["worst_crop_allocentric_dR_over_its_bound"] = worst_ratio
+            grouped_vs_alone["crops_excused_as_ill_conditioned"] = n_excused
+            grouped_vs_alone["rot_p90_over_crops"] = ego_p90
             if args.dtype == "f16":
                 # (the median is taken of the ALLOCENTRIC |dR|: the egocentric one inherits the conditioning of the turn by t, and over the 8 crops
                 # of the two-rank rehearsal it sat at 8.3e-3 with every other figure at a tenth of its bound)
-                lim = (8e-3, None, 6e-2, 6e-2)
-                grouped_vs_alone["bounds"] = {"rot_allo_median_over_crops": lim[0], "rot6d_logits_rel": 3e-2, "trans": lim[2], "size": lim[3],
-                                              "rot_allo_per_crop": "<= 1.5 x sqrt(3) x amplification(rot6d) x |d rot6d| + 1e-3 (givepose_amd/rot_cond.py)"}
-                ok = allo_median < lim[0] and logit_rel < 3e-2 and explained and float(dmax[1]) < lim[2] and float(dmax[2]) < lim[3]
+                # measured on the four workloads: logits 3e-3, t 1.4e-3, s <= 1e-3, egocentric median 2e-3 / p90 6e-3: the bounds are a small
+                # multiple of that (round-4 advice: the returned, egocentric R is gated too, and t / s at 1e-2, not at twice the oracle tolerance)
+                lim = (8e-3, None, 1e-2, 1e-2)
+                grouped_vs_alone["bounds"] = {"rot_allo_median_over_crops": lim[0], "rot_median_over_crops": 8e-3, "rot_p90_over_crops": 2.5e-2,
+                                              "rot6d_logits_rel": 1.5e-2, "trans": lim[2], "size": lim[3], "crops_excused_as_ill_conditioned": 2 * G,
+                                              "rot_allo_per_crop": "<= 1.5 x sqrt(3) x amplification(rot6d) x |d rot6d| + 1e-3; excused only if ill-conditioned by the "
+                                                                   "separate forward's logits alone (givepose_amd/rot_cond.py)"}
+                ok = (allo_median < lim[0] and float(dmax[0]) < 8e-3 and ego_p90 < 2.5e-2 and logit_rel < 1.5e-2 and explained and n_excused <= 2 * G
+                      and float(dmax[1]) < lim[2] and float(dmax[2]) < lim[3])
             else:
                 lim = (2e-5, 1e-4, 2e-5, 2e-5)
                 grouped_vs_alone["bounds"] = dict(zip(("rot_median_over_crops", "rot_max_over_crops", "trans", "size"), lim))
@@ -414,7 +439,9 @@ def main():
     if rank == 0:
         note("serial leg done")
     # ---------------- roofline leg: per-launch hipEvents on the launch stream, eager pass of the serial net
-    if rank == 0 and not args.no_roofline:
+    # (N > 1: EVERY rank runs the leg -- a handful of eager passes -- so that no rank sits in the final RCCL barrier while rank 0 measures;
+    # the line carries rank 0's numbers: its serial eager pass, not the N-rank step)
+    if (rank == 0 or coll) and not args.no_roofline:
         lib = _lib.load()
         graph_was = serial.use_graph
         serial.use_graph = False
@@ -461,7 +488,13 @@ def main():
                             "launches_per_step": g["launches_per_step"], "launches_per_launch_sequence": g["launches_per_launch_sequence"],
                             "avg_launch_us": g["avg_launch_us"],
                             "alg_flop_per_launch": g["alg_flop_per_launch"], "alg_bytes_per_launch": g["alg_bytes_per_launch"],
-                            "kernels": top[:3], "crops_per_launch": BL}
+                            "kernels": top[:3], "crops_per_launch": BL,
+                            "measured_on": "rank 0's serial eager pass of the launch sequence (hipEvents around every launch)" + (" -- not the N-rank step" if world > 1 else ""),
+                            # the chip does not hold 2.4 GHz inside MFMA kernels on random data: in-kernel s_memtime / s_memrealtime stamps
+                            # (investigation build, scripts/kernel_clock.py) read 1.63-1.83 GHz; the fp16 MFMA rate AT THAT CLOCK is what the
+                            # matrix pipe can deliver, and `frac_at_held_clock` prices the class against it (peak stays the guide's 2.5 PFLOP/s)
+                            "held_clock": {"ghz_in_kernel": [1.63, 1.83], "source": "profiles/r05_kernel_clock.txt", "peak_at_held_clock": [round(peak * 1.63 / 2.4), round(peak * 1.83 / 2.4)],
+                                           "frac_at_held_clock": [round(g["tflops"] / (peak * 1.83 / 2.4), 3), round(g["tflops"] / (peak * 1.63 / 2.4), 3)]} if args.dtype != "f32" else None}
         if "dcnv3" in classes:
             d = classes["dcnv3"]
             line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
@@ -626,6 +659,19 @@ def main():
     if rank == 0:
         if commit:
             line["commit"] = commit
+        # the driver keeps the END of this (long) line: the figures a reader needs first, once more, last
+        g = lambda k, f: (line.get(k) or {}).get(f)
+        vf = line.get("vs_float64") or {}
+        line["summary"] = {
+            "value": line["value"], "value_min": line["value_min"], "value_max": line["value_max"], "timed_regions": n_regions, "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen, "ms_per_step": line["ms_per_step"], "dtype": line["dtype"],
+            "one_batch_in_flight_bs64_serial": g("one_batch_in_flight", "value"), "one_launch_in_flight": g("one_launch_in_flight", "value"),
+            "roofline_frac_gemm_class": g("roofline", "frac"), "roofline_frac_at_held_clock": (g("roofline", "held_clock") or {}).get("frac_at_held_clock"),
+            "timed_mode_vs_oracle_rot_median_worst": [g("vs_reference", "rot_median_over_crops"), g("vs_reference", "rot")],
+            "parity_mode_images_per_s": g("parity_mode", "value"), "parity_mode_vs_oracle_rot_trans_size": [(g("parity_mode", "vs_reference") or {}).get(k) for k in ("rot", "trans", "size")],
+            "parity_mode_vs_float64_rot": (vf.get("parity_mode") or {}).get("rot"), "fp32_oracle_vs_float64_rot": (vf.get("reference_fp32_cpu") or {}).get("rot"),
+            "latency_b1_ms": g("latency_b1", "ms"), "latency_b4_ms": g("latency_b4", "ms"), "cpu_baseline_images_per_s": g("cpu_baseline", "value"),
+            "cpu_cores": g("cpu_baseline", "cores")}
         print(json.dumps(line), flush=True)
     if coll:
         barrier()

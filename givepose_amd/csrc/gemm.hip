@@ -712,22 +712,20 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         // never stored), so no zero page and no per-lane select is needed.
         const bool sdma = !p.conv && (long)BM * p.ldx * sizeof(T) < (1l << 31) && (long)BN * p.K * sizeof(T) < (1l << 31);
         unsigned xo[XI], wo[WI];
-        // TIMING HACK (round 5 probe): dbg 6 = W addressed as K-blocked [N/16][K/32][16][32], dbg 7 = X too (wrong results)
-        const bool kbw = p.dbg == 6 || p.dbg == 7, kbx = p.dbg == 7;
-        const long kblk = p.K / 32;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int r = min((i * NW + wave) * RPI + lrow, p.M - 1 - m0);
-            xo[i] = kbx ? (unsigned)((long)(i * NW + wave) * kblk * 1024 + lrow * 64 + lchunk * 16) : (unsigned)(((long)r * p.ldx + lchunk * EPT) * sizeof(T));
+            xo[i] = (unsigned)(((long)r * p.ldx + lchunk * EPT) * sizeof(T));
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int r = min((i * NW + wave) * RPI + lrow, p.N - 1 - n0);
-            wo[i] = kbw ? (unsigned)((long)(i * NW + wave) * kblk * 1024 + lrow * 64 + lchunk * 16) : (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
+            wo[i] = (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
         }
-        const char* xtile = kbx ? reinterpret_cast<const char*>(X) + (long)(m0 / 16) * kblk * 1024 : reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
-        const char* wtile = kbw ? reinterpret_cast<const char*>(W) + (long)(n0 / 16) * kblk * 1024 : reinterpret_cast<const char*>(W + (long)n0 * p.K);
-        const long xstep = kbx ? 1024 : RB, wstep = kbw ? 1024 : RB;
+        // (round 5: addressing both operands K-blocked -- every LDS-DMA instruction 1 KB contiguous -- was timed here and bought 2-4 %:
+        // profiles/r05_kblock_probe.txt; the arms are gone again)
+        const char* xtile = reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
+        const char* wtile = reinterpret_cast<const char*>(W + (long)n0 * p.K);
         auto stage_s = [&](int buf, int kt) {
             const unsigned xs = lds0 + buf * STAGE + wave * 1024;
             const unsigned ws = xs + BM * RB;
@@ -738,8 +736,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 xadd = seg == 1 ? p.xplane_b : 0;
                 wadd = seg == 0 ? p.wplane_b : 0;
             }
-            const char* bx = xtile + (long)kt * xstep + xadd;
-            const char* bw = wtile + (long)kt * wstep + wadd;
+            const char* bx = xtile + (long)kt * RB + xadd;
+            const char* bw = wtile + (long)kt * RB + wadd;
 #pragma unroll
             for (int i = 0; i < XI; ++i) glds16_s(bx, xo[i], xs + i * NW * 1024);
 #pragma unroll
@@ -987,10 +985,8 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
     const int lrow = lane >> 2;
     const int wchunk = (lane & 3) ^ ((-(lrow >> 2)) & 3);
     unsigned woff[WPI];        // per-lane byte offsets inside W; the K step's offset goes into the scalar base
-    const bool kbw = p.dbg == 6 || p.dbg == 5, kbx = p.dbg == 5;   // TIMING HACK (round 5 probe, wrong results): K-blocked W / channel-planar X addressing
 #pragma unroll
-    for (int i = 0; i < WPI; ++i) woff[i] = kbw ? (unsigned)(((n0 / 16 + i * 8 + wave) * (p.K / 32)) * 1024 + lrow * 64 + wchunk * 16)
-                                                : (unsigned)(((n0 + (i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
+    for (int i = 0; i < WPI; ++i) woff[i] = (unsigned)(((n0 + (i * 8 + wave) * 16 + lrow) * p.K + wchunk * 8) * 2);
     // window DMA instruction wave + 8 j: pixel 16 i + lane / 4, physical chunk lane & 3.  32-bit byte offsets from the
     // image base (scalar); halo / border lanes point at the zero page instead (xvalid)
     unsigned xoff[XJ];
@@ -1004,7 +1000,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         const int gy = h0 - 1 + wy, gx = wx - 1;
         const int lc = (lane & 3) ^ (((px >> 2) & 1) << 1);
         const bool ok = i < NI && px < NP && wx < WIMG + 2 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)WIMG;
-        xoff[j] = !ok ? 0u : kbx ? (unsigned)((gy * WIMG + gx) * 64 + lc * 16) : (unsigned)(((gy * WIMG + gx) * Cin + lc * 8) * 2);
+        xoff[j] = ok ? (unsigned)(((gy * WIMG + gx) * Cin + lc * 8) * 2) : 0u;
         if (ok) xvalid |= 1u << j;
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
@@ -1012,7 +1008,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         int cc = g;
         long plane = 0;
         if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 0 ? p.wplane_b : 0; }
-        const char* base = reinterpret_cast<const char*>(W) + plane + (kbw ? (tap * (Cin >> 5) + cc) * 1024 : (tap * Cin + cc * 32) * 2);
+        const char* base = reinterpret_cast<const char*>(W) + plane + (tap * Cin + cc * 32) * 2;
         const unsigned d = lds0 + buf * WST + wave * 1024;
         glds16_s(base, woff[0], d);
         if constexpr (WPI == 2) glds16_s(base, woff[WPI - 1], d + 8192);
@@ -1022,7 +1018,7 @@ __global__ __launch_bounds__(512) void conv3_pp_kernel(const GemmKP p) {
         long plane = 0;
         if constexpr (SPL) { const int seg = (g >= NCC ? 1 : 0) + (g >= 2 * NCC ? 1 : 0); cc = g - seg * NCC; plane = seg == 1 ? p.xplane_b : 0; }
         const unsigned d = lds0 + WIN0 + (g & 1) * WINB + (wave + 8 * j) * 1024;
-        const char* src = ximg + plane + xoff[j] + (kbx ? cc * (p.H * WIMG * 64) : cc * 64);
+        const char* src = ximg + plane + xoff[j] + cc * 64;
         glds16((xvalid >> j) & 1 ? src : zp, d);
     };
 

@@ -1,4 +1,5 @@
-"""Round-5 probe: what whole-line (K-blocked / channel-planar) operand ADDRESSING buys the LDS-DMA kernels.  Timing only: the dbg arms
+"""Round-5 probe (the dbg arms it drives -- variants 610 / 710 / 613 / 513 -- were removed from the library after the measurement: profiles/r05_kblock_probe.txt).
+What whole-line (K-blocked / channel-planar) operand ADDRESSING buys the LDS-DMA kernels.  Timing only: the dbg arms
 read the same buffers in a permuted order (wrong results).  Interleaved medians, one process, one device.
   gemm v10 / 610 (W blocked) / 710 (X and W blocked);  conv v13 / 613 (W blocked) / 513 (W blocked, X planar)."""
 import os, sys, statistics, torch

@@ -86,8 +86,9 @@ def test_grouped_launch_equals_separate_batches(mode):
     both = _cat([b0, b1])
     grouped = PoseNet(cfg, seed=0, dcn_couple=8, **MODES[mode]).cuda()
     alone = PoseNet(cfg, seed=0, **MODES[mode]).cuda()
-    og = {k: v.clone() for k, v in grouped.forward_device(both).items() if k in KEYS}
-    oa = [{k: v.clone() for k, v in alone.forward_device(b).items() if k in KEYS} for b in (b0, b1)]
+    keep = KEYS + ("rot6d", "rot_allo")
+    og = {k: v.clone() for k, v in grouped.forward_device(both).items() if k in keep}
+    oa = [{k: v.clone() for k, v in alone.forward_device(b).items() if k in keep} for b in (b0, b1)]
     same_schedules = _labels(grouped, both) == _labels(alone, b0)
     for g in range(2):
         sl = slice(8 * g, 8 * g + 8)
@@ -98,8 +99,18 @@ def test_grouped_launch_equals_separate_batches(mode):
         # two numerically equivalent builds of the mode -- over ALL crops, R, t, s and both coordinate maps.
         bit = all(torch.equal(og[k][sl], oa[g][k]) for k in KEYS)
         print(f"   bitwise: {bit}")
-        tol = 3e-2 if mode == "f16" else 5e-5
-        assert all(v < tol for v in d.values()), (g, d)
+        if mode == "f16":
+            # two numerically equivalent schedules of the fp16 mode: the rot6d logits (what the network computes), t, s and the coordinate maps
+            # tightly; every crop's allocentric |dR| within what its own logit difference and conditioning explain (givepose_amd/rot_cond.py);
+            # the maximum of the egocentric |dR| over the crops is the worst-conditioned crop's and gets no ceiling of its own
+            lg = float((og["rot6d"][sl].float() - oa[g]["rot6d"].float()).abs().max() / oa[g]["rot6d"].float().abs().max())
+            bnd = rot_error_bound(oa[g]["rot6d"].float().cpu(), og["rot6d"][sl].float().cpu(), max_logit_err=1.5e-2 * float(oa[g]["rot6d"].float().abs().max()))
+            per_u = (og["rot_allo"][sl].float().cpu().reshape(8, -1) - oa[g]["rot_allo"].float().cpu().reshape(8, -1)).abs().max(1).values.double()
+            print(f"   rot6d logits rel {lg:.2e}; allocentric |dR| / bound max {float((per_u / bnd).max()):.3f}")
+            assert lg < 1.5e-2 and bool((per_u <= bnd).all()), (g, lg, per_u, bnd)
+            assert d["trans"] < 1e-2 and d["size"] < 1e-2 and d["nocs_coor"] < 2e-2 and d["ivfc_coor"] < 2e-2, (g, d)
+        else:
+            assert all(v < 5e-5 for v in d.values()), (g, d)
         ref = _oracle(cfg, (b0, b1)[g])
         e = _errs(og, ref, sl)
         print(f"grouped vs oracle [{mode}] group {g}", e)
@@ -166,7 +177,8 @@ def test_grouped_launch_bs128_matches_oracle_per_batch(oracle_2x64, mode):
             # blend began to round once instead of twice): it gets no ceiling of its own.
             r6d = dev["rot6d"][sl].float().cpu()
             r6 = float((r6d - ref["rot6d"]).abs().max() / ref["rot6d"].abs().max())
-            bound = rot_error_bound(ref["rot6d"], r6d)
+            bound = rot_error_bound(ref["rot6d"], r6d, max_logit_err=1.5e-2 * float(ref["rot6d"].abs().max()))   # inf only where the reference's logits alone excuse the crop
+            assert int(torch.isinf(bound).sum()) <= 2, (g, int(torch.isinf(bound).sum()))
             per_u = (dev["rot_allo"][sl].float().cpu().reshape(64, -1) - ref["rot_allo"].reshape(64, -1)).abs().max(1).values.double()   # allocentric: the map the bound is for
             worst = int(per_u.argmax())
             print(f"   rot6d logits rel {r6:.2e}; worst crop {worst}: |dR| {float(per_u[worst]):.3e}, explained up to {float(bound[worst]):.3e}")
@@ -190,6 +202,24 @@ def test_single_batch_bs64_second_seed_meets_1e_4(oracle_2x64, mode):
     print(f"bs64 seed 641 [{mode}] vs fp32 oracle {e} vs float64 {e64} (fp32 oracle vs float64: rot {noise:.2e})")
     assert e64["rot"] < 1e-4 and e64["trans"] < 1e-4 and e64["size"] < 1e-4, e64
     assert e["rot"] < 1e-4 + noise and e["trans"] < 1e-4 and e["size"] < 1e-4, (e, noise)
+
+
+@pytest.mark.parametrize("seed", [642, 643, 644, 645])
+def test_split_mode_bs64_more_seeds_meet_1e_4_against_float64(seed):
+    """Round-4 review: the split-operand mode meets north_star's 1e-4 against the fp32 CPU oracle with 7 % of margin on the bench batch, and
+    the asserts above compare with `1e-4 + (fp32 oracle - float64 oracle)` because that oracle's own rounding error on its worst-conditioned
+    crop is of the size of the bar.  Here: four MORE batch seeds at bs = 64 against the oracle run in FLOAT64, the plain < 1e-4 on R / t / s
+    with no noise term -- so that the margin against the fp32 oracle cannot hide a seed at 1.2e-4."""
+    from givepose_amd import PoseNet, PoseNetConfig
+    cfg = PoseNetConfig()
+    b = _batch(64, seed)
+    ref64 = _oracle(cfg, b, f64=True)
+    net = PoseNet(cfg, seed=0, **MODES["split"]).cuda()
+    out = net(b, "cuda")
+    e64 = {k: float((out[k].double().cpu() - ref64[k].double()).abs().max()) for k in ("rot", "trans", "size")}
+    per = (out["rot"].double().cpu() - ref64["rot"].double()).abs().reshape(64, -1).max(1).values.sort().values
+    print(f"split bs64 seed {seed} vs float64 oracle: {e64}; per-crop |dR| median {float(per[32]):.2e} p90 {float(per[57]):.2e}")
+    assert e64["rot"] < 1e-4 and e64["trans"] < 1e-4 and e64["size"] < 1e-4, (seed, e64)
 
 
 @pytest.mark.parametrize("use_dcn", ["", "dcnv3"])

@@ -535,6 +535,39 @@ def test_dwconv_ln(dt, C, H, KS):
     assert float((out2[n:] - 7.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("C,H,KS,B,offset", [(256, 32, 7, 3, 0.0), (512, 16, 7, 13, 0.0), (512, 16, 7, 128, 0.0), (128, 64, 7, 1, 0.0),
+                                             (256, 64, 3, 2, 0.0), (1024, 8, 7, 32, 0.0), (512, 16, 7, 13, 50.0), (256, 32, 7, 3, 50.0)])
+def test_dwconv_ln_fp16_kernels_by_grid_size(C, H, KS, B, offset):
+    """test_dwconv_ln runs B = 2, where gp_dwconv_ln's routing (dw_mfma_min_wgs: 33 workgroups at C = 256, 52 at C = 512) sends C = 256 / 512
+    to the 2-pixel strip kernel: the round-4 MFMA tiling (two output rows x eight channels per MFMA, row-parity swizzle, one-pass
+    LayerNorm) had no operator-level test for NSLAB = 2 / 4 (round-4 advice).  Here: batches that reach dwconv7_ln_mfma_kernel<2>, <4, NBUF 2>
+    (52 ... 511 workgroups) and <4, NBUF 1> (>= 512), the fp16 8-pixel strip kernel with >= 128 workgroups (dw3x3 at 64 x 64, C = 1024), and
+    -- offset 50 -- channel vectors whose mean is ~50 x their standard deviation (the one-pass variance E[x^2] - mean^2 of the MFMA kernel)."""
+    o = ops()
+    dt = torch.float16
+    x = q(rnd(B, C, H, H, seed=130), dt)
+    w = q(rnd(C, 1, KS, KS, seed=131, scale=(0.02 if offset else 1.0) / KS), dt)
+    b = rnd(C, seed=132, scale=0.1) + offset
+    lw, lb = 1 + 0.1 * rnd(C, seed=133), 0.1 * rnd(C, seed=134)
+    y = F.conv2d(x, w, b, padding=KS // 2, groups=C).permute(0, 2, 3, 1)
+    if offset:
+        sd, mu = y.std(-1), y.mean(-1).abs()
+        assert float((mu / sd).median()) > 30      # the case really is |mean| >> std
+    ref = F.layer_norm(y, (C,), lw, lb, 1e-6)
+    act = o.ACT_GELU if KS == 3 else o.ACT_NONE
+    if KS == 3:
+        ref = F.gelu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    out = torch.zeros(B, H, H, C, dtype=dt, device="cuda")
+    o.dwconv_ln(xd, w.reshape(C, KS * KS).t().contiguous().to("cuda", dt), b.cuda(), lw.cuda(), lb.cuda(), out, KS, act=act)
+    # offset case: the conv output itself is rounded to fp16 nowhere (fp32 accumulators feed the LayerNorm), but x - mean cancels ~6 bits:
+    # a one-pass variance in fp32 keeps ~1e-3 relative on the variance at |mean| / std = 50
+    assert rel_err(out, ref) < (4 * TOL[dt] if offset else TOL[dt]), rel_err(out, ref)
+    out2 = torch.zeros_like(out)      # bitwise repeatable
+    o.dwconv_ln(xd, w.reshape(C, KS * KS).t().contiguous().to("cuda", dt), b.cuda(), lw.cuda(), lb.cuda(), out2, KS, act=act)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("C", [128, 256, 512])
 def test_layernorm(dt, C):

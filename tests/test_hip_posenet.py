@@ -176,7 +176,10 @@ def test_fp16_bs64_close_to_oracle(oracle64, use_dcn):
     from givepose_amd.rot_cond import rot_error_bound
     nB = out["rot"].shape[0]       # (allocentric R: the 6-D -> matrix map the bound is for; the egocentric turn that follows depends on t as well)
     per_u = (dev_out["rot_allo"].float().cpu().reshape(nB, -1) - ref["rot_allo"].reshape(nB, -1)).abs().max(1).values.double()
-    bound = rot_error_bound(ref["rot6d"], rot6d)
+    # (a crop is excused from the bound only if the REFERENCE's logits alone say it is ill-conditioned for a logit error of the size just
+    # asserted; a well-conditioned crop that moved far gets bound 0 and fails; at most 2 of the 64 crops may be excused)
+    bound = rot_error_bound(ref["rot6d"], rot6d, max_logit_err=1.5e-2 * float(ref["rot6d"].abs().max()))
+    assert int(torch.isinf(bound).sum()) <= 2, int(torch.isinf(bound).sum())
     assert bool((per_u <= bound).all()), float((per_u / bound).max())
     assert err["size"] < 3e-2
     assert err["trans"] < 3e-2 * max(1.0, float(ref["trans"].abs().max()))
@@ -373,12 +376,12 @@ def test_attention_encoder_variant_bs32_matches_oracle(mode, tol):
 
 def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
     """Dispatch guard: at the bench shape the fp16 path must run the schedules DESIGN.md prices -- stage-2 fc1 with its weights
-    in registers (variant 17), the 3x3 head convs on the LDS-window kernel (13), stages 0-1 on the fused MLP -- and the
+    in registers (variant 21: two accumulator sets, GELU on packed fp16; round 4: 17), the 3x3 head convs on the LDS-window kernel (13), stages 0-1 on the fused MLP -- and the
     split-operand mode their split forms.  (Round 3 once lost variant 16 to an if / else slip: -5 % end to end, no test noticed.)"""
     from givepose_amd import PoseNet, PoseNetConfig
     lab = _launch_labels(net16, _batch(64, 3))
     n = lambda key: sum(v for l, v in lab.items() if key in l)
-    assert n("gemm v17 M16384 N2048 K512 epi1") == 27, lab
+    assert n("gemm v21 M16384 N2048 K512 epi1") == 27, lab
     assert n("conv3x3 s1 v13 64x64") == 4 and n("conv3x3 s1 v13 32x32") == 4, lab
     assert n("convnext_mlp C128") == 3 and n("convnext_mlp C256") == 3, lab
     assert n("N512 K2048 epi4") == 27, lab
