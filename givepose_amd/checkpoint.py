@@ -81,3 +81,81 @@ def load_checkpoint(net, state_dict, strict=True, verbose=True, report_path=None
     if verbose and renamed:
         print(f"[givepose_amd] {len(renamed)} checkpoint keys renamed, e.g. {next(iter(renamed.items()))}")
     return {"renamed": renamed, "missing": [k for k in own if k not in sd], "unknown": unknown}
+
+
+EXPECTED_KEYS_FILE = "tests/golden/expected_checkpoint_keys.txt"
+
+
+def expected_keys(cfg=None):
+    """[(key, shape)] of everything `PoseNet(cfg)` registers, in registration order: what a released checkpoint has to provide (or a
+    subset of it: evaluate.py:53-56 updates the model's own dict).  `backbone.*` follows the timm 0.9.6 `FeatureListNet` flattening as
+    this package understands it -- the one part no fixture of the reference pins (module docstring)."""
+    from .config import PoseNetConfig
+    from .posenet import PoseNet
+    net = PoseNet(cfg or PoseNetConfig(), dtype=torch.float32, seed=0)
+    return [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+
+
+def diff_keys(state_dict, expected):
+    """A checkpoint's keys against the expected list (after `remap_keys`): -> dict(renamed, unknown, missing, shape_mismatch)."""
+    sd, renamed = remap_keys(state_dict)
+    exp = dict(expected)
+    return {"renamed": renamed,
+            "unknown": [(k, tuple(getattr(v, "shape", ()))) for k, v in sd.items() if k not in exp],
+            "missing": [(k, s) for k, s in expected if k not in sd],
+            "shape_mismatch": [(k, tuple(sd[k].shape), exp[k]) for k in sd if k in exp and tuple(sd[k].shape) != tuple(exp[k])]}
+
+
+def _read_expected(path):
+    out = []
+    for line in open(path):
+        if line.strip() and not line.startswith("#"):
+            k, s = line.rstrip("\n").split("\t")
+            out.append((k, tuple(int(x) for x in s.split("x")) if s != "scalar" else ()))
+    return out
+
+
+def main(argv=None):
+    """python -m givepose_amd.checkpoint <checkpoint.pth> [expected_keys.txt]   -- one command for a user who HAS the released weights
+    (README.md:55 of the reference; none is reachable offline): prints what the checkpoint calls differently from the committed list
+    (tests/golden/expected_checkpoint_keys.txt), what it carries that nothing expects and what it lacks.  CPU only.
+    python -m givepose_amd.checkpoint --write <expected_keys.txt>            -- regenerate the list from the module."""
+    import os
+    import sys
+    argv = sys.argv[1:] if argv is None else argv
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if argv and argv[0] == "--write":
+        path = argv[1] if len(argv) > 1 else os.path.join(root, EXPECTED_KEYS_FILE)
+        with open(path, "w") as f:
+            f.write("# every tensor PoseNet(PoseNetConfig()) registers: <key>\\t<shape>; backbone.* = timm 0.9.6 FeatureListNet(convnext_base) names as this package\n"
+                    "# understands them (UNVERIFIED against timm: not installed, no released checkpoint reachable).  python -m givepose_amd.checkpoint <ckpt> diffs a checkpoint against it.\n")
+            for k, s in expected_keys():
+                f.write(k + "\t" + ("x".join(str(d) for d in s) if s else "scalar") + "\n")
+        print("wrote", path)
+        return 0
+    if not argv:
+        print(main.__doc__)
+        return 2
+    exp = _read_expected(argv[1] if len(argv) > 1 else os.path.join(root, EXPECTED_KEYS_FILE))
+    ck = torch.load(argv[0], map_location="cpu")
+    for key in ("state_dict", "model", "network"):       # common wrappers
+        if isinstance(ck, dict) and key in ck and isinstance(ck[key], dict):
+            ck = ck[key]
+    d = diff_keys(ck, exp)
+    print(f"{len(ck)} checkpoint tensors, {len(exp)} expected; {len(d['renamed'])} renamed, {len(d['unknown'])} unknown, {len(d['missing'])} missing, "
+          f"{len(d['shape_mismatch'])} shape mismatches")
+    for a, b in list(d["renamed"].items())[:20]:
+        print("  renamed ", a, "->", b)
+    for k, s in d["unknown"]:
+        print("  UNKNOWN ", k, s)
+    for k, s in d["missing"][:12]:
+        print("  missing ", k, s)
+    if len(d["missing"]) > 12:
+        print(f"  ... and {len(d['missing']) - 12} more missing (a partial checkpoint is fine: evaluate.py:53-56 updates the model's own dict)")
+    for k, a, b in d["shape_mismatch"]:
+        print("  SHAPE   ", k, "checkpoint", a, "expected", b)
+    return 1 if d["unknown"] or d["shape_mismatch"] else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

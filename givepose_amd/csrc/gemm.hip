@@ -2242,7 +2242,9 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // 32 us flat up to 4 096 rows): the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm
     // statistics need the 64-row tile.
     int sm_mt = 0;
-    if (smallm_ok && smallm_enabled()) {
+    // (the estimate below was fitted on 1-8 crops: the automatic choice stops at 32 768 rows -- 16 crops' worth of the widest map it was
+    // measured on -- whatever the estimate says beyond; tests/test_hip_posenet.py pins which launches take it at 4 / 8 / 16 crops)
+    if (smallm_ok && smallm_enabled() && d->M <= 32768) {
         double best = 1e30;
         for (int mt = d->gn_partial ? 4 : 1; mt <= 4; mt *= 2) {
             if (d->M % (16 * mt)) continue;
@@ -2303,6 +2305,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 18) {
         GP_REQUIRE(smallm_ok, "gp_gemm: variant 18 needs a plain fp16 GEMM / conv (fp16 out, no split-K), N %% 32 == 0, M %% 16 == 0 (%% 64 with fused GroupNorm statistics)");
+        GP_REQUIRE(d->M / (16 * (d->gn_partial ? 4 : sm_mt)) <= 65535, "gp_gemm: variant 18: M=%d gives more than 65535 row tiles (grid.y)", d->M);
         if (d->gn_partial) { if (d->KH > 0) launch_smallm<4, 2, true, true>(p, s); else launch_smallm<4, 2, false, true>(p, s); }
         else if (d->KH > 0) { if (sm_mt == 4) launch_smallm<4, 2, true, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, true, false>(p, s); else launch_smallm<1, 2, true, false>(p, s); }
         else { if (sm_mt == 4) launch_smallm<4, 2, false, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, false, false>(p, s); else launch_smallm<1, 2, false, false>(p, s); }

@@ -78,3 +78,22 @@ def test_checkpoint_key_report(tmp_path):
     assert len(doc["missing"]) == len(sd) - 6 and doc["shape_mismatch"] == []
     out = load_checkpoint(net, {("module." + k): sd[k] for k in some}, verbose=False, report_path=str(rep))
     assert len(out["renamed"]) == 6 and json.load(open(rep))["unknown"] == []
+
+
+def test_expected_checkpoint_key_list_is_current(tmp_path):
+    """tests/golden/expected_checkpoint_keys.txt (what a user with the released weights diffs their checkpoint against,
+    `python -m givepose_amd.checkpoint <ckpt>`) is exactly what PoseNet registers; the diff reports renames / unknown / missing keys."""
+    import torch
+    from givepose_amd import checkpoint as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = C._read_expected(os.path.join(root, C.EXPECTED_KEYS_FILE))
+    assert exp == C.expected_keys()
+    sd = {k: torch.zeros(s) for k, s in exp[:40]}
+    sd["module.backbone.stem.0.weight"] = sd.pop("backbone.stem_0.weight")      # DataParallel prefix + un-flattened timm name
+    sd["not.a.key"] = torch.zeros(2)
+    d = C.diff_keys(sd, exp)
+    assert d["renamed"] == {"module.backbone.stem.0.weight": "backbone.stem_0.weight"} and [k for k, _ in d["unknown"]] == ["not.a.key"]
+    assert len(d["missing"]) == len(exp) - 40 and not d["shape_mismatch"]
+    f = tmp_path / "ck.pth"
+    torch.save({"state_dict": sd}, f)
+    assert C.main([str(f)]) == 1

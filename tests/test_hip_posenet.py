@@ -9,6 +9,8 @@ Tolerances (north_star: 1e-4 abs on R/t/s):
       maps <= 2e-2 abs -- fp16 operand rounding (weights alone: 1.5e-3 on R); reported, not claimed to meet 1e-4.
 """
 import numpy as np
+import re
+
 import pytest
 import torch
 
@@ -390,6 +392,21 @@ def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
     assert m("gemm v10 M16384 N2048 K512 epi1 split3") == 27 and m("gemm v7 M16384 N512 K2048 epi4 split3") == 27, sp
     assert m("conv3x3 s1 v13 64x64 Cin256 Cout256 M262144 +gn split3") == 4, sp
     assert m("split_planes") <= 30, sp          # only the small tensors still take a split pass
+
+
+@pytest.mark.parametrize("B,pins", [
+    (4, {"gemm v7 M1024 N2048 K512 epi1": 27, "gemm v18 M1024 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v18 32x32": 4, "conv3x3 s1 v18 16x16": 4}),
+    (8, {"gemm v7 M2048 N2048 K512 epi1": 27, "gemm v18 M2048 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4}),
+    (16, {"gemm v7 M4096 N2048 K512 epi1": 27, "gemm v7 M4096 N512 K2048 epi4": 27, "conv3x3 s1 v13 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4})])
+def test_small_batch_wiring_is_pinned(net16, B, pins):
+    """Dispatch guard for the batches between the latency path and the bench shape (round-4 advice): the automatic choice between the latency
+    kernel (variant 18, cost model fitted on 1-8 crops, capped at 32 768 rows) and the tile kernels moves a whole forward by tens of percent
+    and no numerics test notices.  The launches that carry a forward at 4 / 8 / 16 crops, as measured when the model was fitted
+    (profiles/r04_small_m_tiles.txt; the labels of round 5: scripts/dump_labels.py)."""
+    lab = _launch_labels(net16, _batch(B, 3))
+    for key, n in pins.items():
+        assert sum(v for l, v in lab.items() if key in l) == n, (key, lab)
+    assert not any(" v18 " in l and int(re.search(r" M(\d+)", l).group(1)) > 32768 for l in lab), lab
 
 
 def test_grouped_launches_in_flight_bs128_stress():
