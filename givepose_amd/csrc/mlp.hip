@@ -45,6 +45,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_sb(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
 }
@@ -268,6 +277,246 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
     }
 }
 
+// =====================================================================================================
+// The same block for C = 512 (ConvNeXt stage 2: 27 of the 36 blocks; round 5), ONE wave per SIMD.
+// The two-launch path runs fc1 on the weights-in-registers kernel and fc2 on the ping-pong tile kernel: 134 MB of hidden activations
+// (128 crops) are stored and fetched again, both kernels pay a prologue / epilogue with the matrix pipe idle, and fc2's 256 epilogues hit
+// HBM in lock step.  Here a workgroup of FOUR waves (256 threads: up to 512 registers per wave) owns 128 rows: a wave keeps its 32 x rows as
+// B fragments (128 registers) and the whole 32 x 512 output tile as accumulators (256 registers), and walks the 2048 hidden units in 64
+// chunks of 32: GEMM1 (64 MFMAs: A = W1 fragments from LDS) -> GELU (packed fp16, common.hpp) -> GEMM2 (64 MFMAs: A = W2p fragments, B = the
+// GELU output as it stands in registers).  With one wave per SIMD nothing else hides a latency, so the loop is software-pipelined INSIDE the
+// wave: iteration c runs GEMM1 of chunk c+1 with the GELU of chunk c riding behind its MFMAs (two hidden accumulator sets), then GEMM2 of
+// chunk c; fragment reads are issued one MFMA group ahead.
+// Weights stream through a 4-slot LDS ring of 32 KB PIECES in consumption order -- W1[0], then W1[c+1], W2[c] for every c -- by LDS-DMA, three
+// pieces ahead, one barrier per piece in the MIDDLE of the phase before it (mid() below: RAW for the next piece, WAR for the slot of the previous one).
+__global__ __launch_bounds__(256) void convnext_mlp512_kernel(const MlpKP p) {
+    constexpr int C = 512, HD = 2048, NCH = HD / 32, KS = C / 32, CT = C / 16, MT = 2, NW = 4;
+    constexpr int ROWB = C * 2, PIECE = 32768, NP = 4, LEAD = 3, NPIECES = 2 * NCH, IPW = PIECE / 1024 / NW;   // 8 DMA instructions per wave and piece
+    constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
+    constexpr int RING = NP * PIECE, SMEM = (RING + HD * 4) > NW * SLAB ? (RING + HD * 4) : NW * SLAB;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * 128 + wave * 32;
+
+    float* b1s = reinterpret_cast<float*>(smem + RING);
+    for (int i = tid; i < HD / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+
+    // ---- this wave's x rows as B fragments: lane (fr, fq) holds x[m][ks*32 + fq*8 .. +8]
+    uint4 xf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            xf[mt][ks] = *reinterpret_cast<const uint4*>(p.X + (m0 + mt * 16 + fr) * C + ks * 32 + fq * 8);
+
+    // ---- DMA sources.  W1 piece image: [32 rows][1 KB], 16-byte chunk ^= row & 15 (one instruction = one row); W2 piece image:
+    //      [512 rows][64 B], chunk ^= (-(row >> 2)) & 3 inside each group of 16 rows (one instruction = 16 rows)
+    //      Instruction i of a wave: W1 row 4 i + wave, chunk lane ^ ((4 i + wave) & 15) = (lane ^ wave) ^ (4 (i & 3)) (wave < 4): ONE offset register,
+    //      the row term 4 i KB goes into the scalar base; W2 rows (4 i + wave) * 16 + lane / 4: likewise one register + a scalar term.
+    const unsigned w1off = (unsigned)(wave * ROWB + ((lane ^ wave) << 4));
+    const int lr = lane >> 2;
+    const unsigned w2off = (unsigned)(((wave * 16 + lr) * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3)) * 2);
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    // piece q of the stream: q = 0 -> W1[0]; odd q < NPIECES - 1 -> W1[(q + 1) / 2]; even q >= 2 -> W2[q / 2 - 1]; q = NPIECES - 1 -> W2[NCH - 1]
+    auto stage_instr = [&](int q, int i) {      // DMA instruction i (of IPW) of this wave for piece q
+        const unsigned d = lds0 + (q & (NP - 1)) * PIECE + wave * 1024 + i * NW * 1024;
+        const bool is_w1 = q == 0 || ((q & 1) && q != NPIECES - 1);
+        if (is_w1) {
+            const int ch = (q + 1) >> 1;
+            glds16_sb(reinterpret_cast<const char*>(p.W1) + (long)ch * 32 * ROWB + i * NW * ROWB, w1off ^ (unsigned)((4 * (i & 3)) << 4), d);
+        } else {
+            const int ch = q == NPIECES - 1 ? NCH - 1 : (q >> 1) - 1;
+            glds16_sb(reinterpret_cast<const char*>(p.W2p) + (long)ch * 64 + (long)i * NW * 16 * HD * 2, w2off, d);
+        }
+    };
+    // Synchronisation, ONE barrier per piece, in the MIDDLE of the phase that consumes piece q (mid(q)): the wave waits for ITS DMA of piece q+1
+    // (counted vmcnt: piece q+2, always the one piece issued after it, stays in flight), the barrier publishes piece q+1 -- so phase q+1 starts
+    // without a barrier, its first fragment reads right behind the last MFMAs of phase q -- and, every wave being at least half way through
+    // phase q, ends all reads of piece q-1, whose slot piece q+3 may then take.
+    auto mid = [&](int q) {
+        if (q + 1 >= NPIECES) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < NPIECES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // The DMA of piece q+3 rides in the second half of phase q: its source (W1 or W2p chunk) is picked with scalar selects, not branches -- control
+    // flow inside the unrolled MFMA stream made hipcc spill 84 registers -- and the phases that have nothing left to fetch are separate
+    // instantiations (RF = false).
+    struct Refill { const char* base; long stride; unsigned voff, xm, dst; };
+    auto refill_of = [&](int qq) {
+        const bool is_w1 = qq == 0 || ((qq & 1) && qq != NPIECES - 1);
+        const int ch = is_w1 ? (qq + 1) >> 1 : (qq == NPIECES - 1 ? NCH - 1 : (qq >> 1) - 1);
+        Refill r;
+        r.base = is_w1 ? reinterpret_cast<const char*>(p.W1) + (long)ch * 32 * ROWB : reinterpret_cast<const char*>(p.W2p) + (long)ch * 64;
+        r.stride = is_w1 ? (long)NW * ROWB : (long)NW * 16 * HD * 2;
+        r.voff = is_w1 ? w1off : w2off;
+        r.xm = is_w1 ? ~0u : 0u;
+        r.dst = lds0 + (qq & (NP - 1)) * PIECE + wave * 1024;
+        return r;
+    };
+    auto refill = [&](const Refill& r, int i) {
+#ifndef GP_MLP512_NODMA     // investigation build: the loop without its in-loop LDS-DMA (wrong results): what the DMA issue costs a lone wave
+        glds16_sb(r.base + i * r.stride, r.voff ^ ((unsigned)((4 * (i & 3)) << 4) & r.xm), r.dst + i * NW * 1024);
+#endif
+    };
+
+    f32x4 acc2[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + ct * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc2[ct][mt] = b;
+    }
+    __syncthreads();   // b1s visible; every compiler-visible global load above has been waited for before the DMA starts
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q)
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) stage_instr(q, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");   // piece 0 (pieces 1, 2 stay in flight)
+    __builtin_amdgcn_s_barrier();
+
+    const int w1fo = fr * ROWB, w2fo = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+    f32x4 acc1[2][MT];           // [nt][mt]: the hidden accumulators of the chunk GEMM1 is working on
+    unsigned xq[8];              // the PREVIOUS chunk's 16 hidden values as 8 packed fp16 pairs (what the GELU in GEMM1's shadow reads):
+                                 // pair c = mt * 4 + nt * 2 + e <-> registers 2 e, 2 e + 1 of acc1[nt][mt] = dword c % 4 of GEMM2's B fragment hb[mt]
+    unsigned hw[8];              // ... and their GELU, packed: the dwords of hb
+    uint4 hb[MT];
+    half2v hx[2], hu[2], hp[2];
+
+    // GEMM1 of chunk ch (W1 piece in ring slot `slot`); SH: the GELU of the previous chunk (xq -> hw) rides behind its MFMAs.  At the end the
+    // chunk's own values are rounded to packed fp16 into xq (the GELU's first step: 8 conversions outside the shadow buy 8 registers --
+    // one hidden accumulator set instead of two; the kernel sits at the 512-register limit).
+    auto gemm1 = [&](int ch, int q, auto shc, auto rf1c, auto rf2c) {
+        constexpr bool RF1 = decltype(rf1c)::value, RF2 = decltype(rf2c)::value;      // fetch piece q+2 in the first half / piece q+3 in the second
+        const int slot = q & (NP - 1);
+        const Refill rp1 = refill_of(RF1 ? q + 2 : 0), rp2 = refill_of(RF2 ? q + 3 : 0);
+        constexpr bool SH = decltype(shc)::value;
+        constexpr int NSL = GELU16_SLICES - 1, NCALL = 8 * NSL, NMF = KS * 4;      // slices 1 .. 12 (slice 0, the conversion, is done)
+        const char* s1 = smem + slot * PIECE + w1fo;
+        uint4 a1[3][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) a1[ks][nt] = *reinterpret_cast<const uint4*>(s1 + nt * 16 * ROWB + (((ks * 4 + fq) ^ fr) << 4));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + ch * 32 + nt * 16 + fq * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (ks + 2 < KS) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) a1[(ks + 2) % 3][nt] = *reinterpret_cast<const uint4*>(s1 + nt * 16 * ROWB + ((((ks + 2) * 4 + fq) ^ fr) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, nt = j / 2, mt = j % 2, i = ks * 4 + j;
+                if constexpr (i == NMF / 2) mid(q);
+                acc1[nt][mt] = mma16(a1[ks % 3][nt], xf[mt][ks], acc1[nt][mt]);
+                if constexpr (RF1 && i < NMF / 2 && i % (NMF / 2 / IPW) == 0) refill(rp1, i / (NMF / 2 / IPW));
+                if constexpr (RF2 && i >= NMF / 2 && (i - NMF / 2) % (NMF / 2 / IPW) == 0) refill(rp2, (i - NMF / 2) / (NMF / 2 / IPW));
+                if constexpr (SH) {
+                    constexpr int n0 = i * NCALL / NMF, n1 = (i + 1) * NCALL / NMF;
+                    static_for<n0, n1>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value, g = n / (2 * NSL), m = n % (2 * NSL), slot_ = m / 2 + 1, chn = m % 2, c = 2 * g + chn;
+                        if constexpr (slot_ == 1) hx[chn] = __builtin_bit_cast(half2v, xq[c]);
+                        gelu16_slice<slot_>(f32x2{0.f, 0.f}, hx[chn], hu[chn], hp[chn]);
+                        if constexpr (slot_ == GELU16_SLICES - 1) hw[c] = __builtin_bit_cast(unsigned, hp[chn]);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        static_for<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value, pmt = c / 4, pnt = (c / 2) & 1, pe = c & 1;
+            xq[c] = __builtin_bit_cast(unsigned, half2v{(half_t)acc1[pnt][pmt][2 * pe], (half_t)acc1[pnt][pmt][2 * pe + 1]});
+        });
+    };
+    // GELU of xq with nothing to hide behind (only the last chunk needs it)
+    auto gelu_plain = [&]() {
+        static_for<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            half2v xh = __builtin_bit_cast(half2v, xq[c]), u, pp;
+            static_for<1, GELU16_SLICES>([&](auto sc) { gelu16_slice<decltype(sc)::value>(f32x2{0.f, 0.f}, xh, u, pp); });
+            hw[c] = __builtin_bit_cast(unsigned, pp);
+        });
+    };
+    // GEMM2 of the chunk whose GELU output sits in hw (W2 piece in ring slot `slot`)
+    auto gemm2 = [&](int q) {
+        const int slot = q & (NP - 1);
+        const char* s2 = smem + slot * PIECE + w2fo;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) hb[mt] = uint4{hw[mt * 4], hw[mt * 4 + 1], hw[mt * 4 + 2], hw[mt * 4 + 3]};
+        uint4 a2[4];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + ct * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, CT>([&](auto ctc) {
+            constexpr int ct = decltype(ctc)::value;
+            if constexpr (ct + 3 < CT) a2[(ct + 3) & 3] = *reinterpret_cast<const uint4*>(s2 + (ct + 3) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ct == CT / 2) mid(q);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[ct][mt] = mma16(a2[ct & 3], hb[mt], acc2[ct][mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // piece 0: W1[0] (pieces 0, 1, 2 are in flight from the prologue)
+    gemm1(0, 0, F_{}, F_{}, F_{});
+    // chunks c = 0 .. NCH-2: piece 2c+1 = W1[c+1] (GEMM1 of chunk c+1 with the GELU of chunk c behind it), piece 2c+2 = W2[c] (GEMM2 of chunk c).
+    // ALL DMA rides in the GEMM1 phases (an LDS-DMA asm inside GEMM2's MFMA stream made hipcc spill 77 registers): phase q = 2c+1 fetches piece
+    // q+2 in its first half (slot of piece q-2: every wave is past phase q-1) and piece q+3 behind its barrier (slot of piece q-1).
+    for (int c = 0; c + 2 < NCH; ++c) {
+        gemm1(c + 1, 2 * c + 1, T_{}, T_{}, T_{});
+        gemm2(2 * c + 2);
+    }
+    gemm1(NCH - 1, NPIECES - 3, T_{}, T_{}, F_{});       // the last piece (W2[NCH-1]) in its first half, nothing after that
+    gemm2(NPIECES - 2);
+    // the last chunk: its GELU has no GEMM1 to ride behind; its W2 piece is the last of the stream
+    gelu_plain();
+    gemm2(NPIECES - 1);
+    __syncthreads();   // every wave is done with the ring: the slabs overlay it
+
+    // ---- epilogue: gamma in the MFMA layout, fp16, transpose through a wave-private LDS slab, + residual, 1 KB rows stored 16 B per lane
+    char* slab = smem + wave * SLAB;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + ct * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc2[ct][mt] * g;
+            half4 o;
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+            *reinterpret_cast<half4*>(slab + (mt * 16 + fr) * PITCH + (ct * 4 + fq) * 8) = o;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+        half8 rres[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i0 + i) * C + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            half8 v = *reinterpret_cast<const half8*>(slab + (i0 + i) * PITCH + lane * 16);
+            v += rres[i];
+            *reinterpret_cast<half8*>(p.out + (m0 + i0 + i) * C + lane * 8) = v;
+        }
+    }
+}
+
 // W2 (C, 4C) -> W2p: inside every block of 32 hidden units, k-slot s = fq*8 + nt*4 + j takes unit nt*16 + fq*4 + j
 __global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -281,7 +530,7 @@ __global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD)
 
 extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream) {
     GP_REQUIRE(w2 && w2p && w2 != w2p, "gp_convnext_mlp_pack_w2: bad pointers");
-    GP_REQUIRE(C == 128 || C == 256, "gp_convnext_mlp_pack_w2: C=%d must be 128 or 256", C);
+    GP_REQUIRE(C == 128 || C == 256 || C == 512, "gp_convnext_mlp_pack_w2: C=%d must be 128, 256 or 512", C);
     const long n = (long)C * 4 * C;
     hipLaunchKernelGGL(mlp_pack_w2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const half_t*>(w2), reinterpret_cast<half_t*>(w2p), C, 4 * C);
@@ -293,9 +542,9 @@ extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* s
 extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
                                const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream) {
     GP_REQUIRE(dtype == GP_F16, "gp_convnext_mlp: fp16 storage only (fp32 runs fc1 / fc2 through gp_gemm)");
-    GP_REQUIRE(C == 128 || C == 256, "gp_convnext_mlp: C=%d must be 128 or 256", C);
+    GP_REQUIRE(C == 128 || C == 256 || C == 512, "gp_convnext_mlp: C=%d must be 128, 256 or 512", C);
     GP_REQUIRE(x && w1 && b1 && w2p && b2 && gamma && residual && out, "gp_convnext_mlp: null operand");
-    GP_REQUIRE(M > 0 && M % 256 == 0, "gp_convnext_mlp: M=%ld must be a positive multiple of 256", M);
+    GP_REQUIRE(M > 0 && M % (C == 512 ? 128 : 256) == 0, "gp_convnext_mlp: M=%ld must be a positive multiple of %d", M, C == 512 ? 128 : 256);
     GP_REQUIRE((((size_t)x | (size_t)w1 | (size_t)w2p | (size_t)residual | (size_t)out | (size_t)b1 | (size_t)b2 | (size_t)gamma) & 15) == 0,
                "gp_convnext_mlp: operands must be 16-byte aligned");
     GP_REQUIRE(x != out, "gp_convnext_mlp: x and out must not alias (out may alias residual)");
@@ -309,6 +558,12 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
     const double bytes = 3.0 * M * C * 2 + 2.0 * 4 * C * C * 2;
     gp_timing_before(s, GP_KC_GEMM, flops, bytes);
     gp_timing_label("convnext_mlp C%d M%ld", C, M);
+    if (C == 512) {
+        const dim3 grid512((unsigned)(M / 128));
+        GP_REQUIRE(gp_gelu16_enabled(), "gp_convnext_mlp: the C = 512 kernel exists with the packed-fp16 GELU only (GP_GELU16=0: run fc1 / fc2 through gp_gemm)");
+        hipLaunchKernelGGL(convnext_mlp512_kernel, grid512, dim3(256), 0, s, p);
+        GP_LAUNCH_CHECK("gp_convnext_mlp");
+    }
     const dim3 grid((unsigned)(M / 256));
     if (gp_gelu16_enabled()) {
         if (C == 128) hipLaunchKernelGGL((convnext_mlp_kernel<128, 1>), grid, dim3(512), 0, s, p);

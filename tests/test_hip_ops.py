@@ -333,13 +333,15 @@ def test_gemm_prefetch_hint_changes_nothing():
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("C", [128, 256])
+@pytest.mark.parametrize("C", [128, 256, 512])
 def test_convnext_mlp_fused(C):
     """Fused fc1 -> GELU -> fc2 -> gamma * . + shortcut against the fp32 formula (hidden rounded to fp16 like the
-    two-GEMM path) and against the two-GEMM HIP path itself; in place over the residual."""
+    two-GEMM path) and against the two-GEMM HIP path itself; in place over the residual.  C = 512: the round-5 one-wave-per-SIMD kernel
+    (128 rows per workgroup: M = 640 = five workgroups, more than one XCD chunk; the library keeps it, PoseNet does not use it:
+    profiles/r05_mlp512_ab.txt)."""
     o = ops()
     dt = torch.float16
-    M, HD = 512, 4 * C
+    M, HD = (640 if C == 512 else 512), 4 * C
     x, res = q(rnd(M, C, seed=81), dt), q(rnd(M, C, seed=82), dt)
     w1, b1 = q(rnd(HD, C, seed=83, scale=C ** -0.5), dt), rnd(HD, seed=84)
     w2, b2 = q(rnd(C, HD, seed=85, scale=HD ** -0.5), dt), rnd(C, seed=86)
