@@ -50,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 311 /* round 4: + gp_groupnorm_upsample2x; 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
+#define GP_ABI_VERSION 320 /* round 5: gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -135,7 +135,10 @@ typedef struct gp_gemm_desc {
                   * tile (the split-K carrier), 5 / 9 = its 4-stage forms, 7 = 128x128 software-pipelined, two workgroups per
                   * CU, 2 / 8 = 256x128, 3 = 256x256, 10 / 11 / 12 = ping-pong 256x256 / 128x256 / 5-stage, 13 = 3x3 window
                   * conv (Cout 256), 16 / 17 = K 512 with the weight slice resident in registers (17: 16-byte stores, needs ldc % 8 == 0 and a
-                  * 16-byte aligned C; the default of stage-2 fc1), 18 = the small-M latency kernel (few rows -- the detections of one
+                  * 16-byte aligned C; the default of stage-2 fc1 until round 4), 19 / 20 / 21 / 22 = 17's arithmetic with two accumulator sets (round 5): 19 / 20 on
+                  * 32x32x16 MFMAs, 22 / 21 on 16x16x32; 20 / 21 apply GP_EPI_GELU on packed fp16 (13 v_pk_* operations per value pair, absolute error of
+                  * one fp16 rounding: DESIGN.md 8.2; refused for the other epilogues); 21 = the default of stage-2 fc1 (22 with GP_GELU16=0),
+                  * 18 = the small-M latency kernel (few rows -- the detections of one
                   * frame: fp16 in / out, N % 32 == 0, M % 16 == 0 (% 64 with gn_partial), plain GEMM or conv; chosen by variant 0 when its
                   * estimate beats the tile kernels'; a split-K request is ignored; 218 / 318 / 418 force the 16 / 32 / 64-row tile).
                   * + 100 n otherwise: timing ablations. */
@@ -181,13 +184,15 @@ int gp_gemm(const gp_gemm_desc* d, void* stream);
 int gp_split_planes(const float* x, void* planes, long rows, int cols, long ldx, long plane_stride, int split_shift,
                     void* stream);
 
-/* Fused ConvNeXt block MLP (fp16 storage, C = 128 or 256): one launch for
+/* Fused ConvNeXt block MLP (fp16 storage, C = 128, 256 or -- round 5, one wave per SIMD, M % 128 == 0, needs the packed-fp16 GELU
+ * (GP_GELU16 != 0), measured slower than gp_gemm x 2 at 128 crops: profiles/r05_mlp512_ab.txt -- 512): one launch for
  *   out = residual + gamma * ( fc2( GELU( fc1(x) ) ) )
  * i.e. timm ConvNeXtBlock.forward's `mlp` + layer scale + shortcut (built by network/backbone.py:36-46); replaces the
  * gp_gemm(GELU) -> gp_gemm(SCALE_RES) pair for the stages whose 4C-wide hidden tensor would otherwise round-trip HBM.
  *   x (M,C) = LayerNorm output, w1 (4C,C), b1 (4C) fp32, b2/gamma (C) fp32, residual/out (M,C) (out may alias
  *   residual, not x); w2p = fc2.weight (C,4C) re-ordered by gp_convnext_mlp_pack_w2 (k-slot order of the MFMA B
- *   fragment that the GELU output forms in registers).  M % 256 == 0; all pointers 16-byte aligned. */
+ *   fragment that the GELU output forms in registers).  M % 256 == 0; all pointers 16-byte aligned.
+ *   The GELU runs on packed fp16 arithmetic (common.hpp gelu16_slice) unless the environment has GP_GELU16=0. */
 int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream);
 int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
                     const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream);
