@@ -722,6 +722,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
             const int r = min((i * NW + wave) * RPI + lrow, p.N - 1 - n0);
             wo[i] = (unsigned)(((long)r * p.K + lchunk * EPT) * sizeof(T));
         }
+        // (round 5: issuing the W pieces of a step's DMA between the MFMAs of the MFMA phase instead of in the load phase -- a PPSPLIT instantiation, no
+        // branch in the MFMA stream -- changed nothing: profiles/r05_pp_split_dma_ab.txt; which wave of a SIMD issues them does not matter)
         // (round 5: addressing both operands K-blocked -- every LDS-DMA instruction 1 KB contiguous -- was timed here and bought 2-4 %:
         // profiles/r05_kblock_probe.txt; the arms are gone again)
         const char* xtile = reinterpret_cast<const char*>(X + (long)m0 * p.ldx);
@@ -760,7 +762,25 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
         if (grp) __builtin_amdgcn_s_barrier();
         int buf = 0, nbuf = LEAD;
         clk_stamp(p, 0);
+        // GP_PP_STAMPS (investigation build, scripts/pp_stamps.py, profiles/r05_pp_stamps.txt): s_memtime stamps of waves 0 and 4 of workgroup 0 inside the steps
+        // 8 .. 23 of the main loop -- 0 phase start, 1 fragment reads issued, 2 DMA issued, 3 own DMA landed (vmcnt), 4 behind the barrier, 5 fragments there
+        // (lgkmcnt), 6 MFMAs issued, 7 behind the second barrier -- into the workspace behind the clock stamps
+#ifdef GP_PP_STAMPS
+#define GP_PPS(k)                                                                                                              \
+        do {                                                                                                                     \
+            if (p.ws && p.splitk <= 1 && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && kt >= 8 && kt < 24) {                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+                unsigned long long t_;                                                                                           \
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                    \
+                reinterpret_cast<unsigned long long*>(p.ws)[4096 + ((wave >> 2) * 16 + (kt - 8)) * 8 + (k)] = t_;                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+            }                                                                                                                    \
+        } while (0)
+#else
+#define GP_PPS(k) do {} while (0)
+#endif
         for (int kt = 0; kt < p.nkt; ++kt) {
+            GP_PPS(0);
             if (p.dbg != 2) {
                 const char* xs = smem + buf * STAGE + xfo;
                 const char* ws = smem + buf * STAGE + BM * RB + wfo;
@@ -770,14 +790,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                 for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const uint4*>(xs + t * 1024 + co);
             }
             __builtin_amdgcn_sched_barrier(0);
+            GP_PPS(1);
             if (kt + LEAD < p.nkt && (p.dbg != 1 || kt + LEAD < NS)) { if (sdma) stage_s(nbuf, kt + LEAD); else stage(nbuf, kt + LEAD); }
+            GP_PPS(2);
             // own DMA of step t+1 landed; steps t+2 .. t+LEAD stay in flight
             if (LEAD == 3 && kt + 3 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
             else if (kt + 2 < p.nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GP_PPS(3);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            GP_PPS(4);
+#ifndef GP_PP_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            GP_PPS(5);
             __builtin_amdgcn_sched_barrier(0);
             split_rescale(kt);
             __builtin_amdgcn_s_setprio(1);
@@ -788,8 +815,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_big_k
                     for (int nt = 0; nt < NT; ++nt) mma<T>(acc[nt][mt], wf[nt], xf[mt]);
             }
             __builtin_amdgcn_s_setprio(0);
+            GP_PPS(6);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            GP_PPS(7);
             __builtin_amdgcn_sched_barrier(0);
             buf = buf + 1 == NS ? 0 : buf + 1;
             nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
