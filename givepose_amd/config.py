@@ -41,6 +41,10 @@ class PoseNetConfig:
     # fp32 -- the downsample conv and every fc2 epilogue write it in fp32 plus an fp16 copy for the depth-wise conv -- so that
     # the fp16 rounding of the stream is not compounded block after block.  Measured: DESIGN.md 5c.
     res_fp32: bool = False
+    # build-side switch (fp16 storage only, round 5): the heads' ConvTranspose2d-as-GEMM writes its (B*64, 9*256) column matrix in fp16 (the GEMM's lean
+    # epilogue) instead of fp32, and gp_deconv_col2im sums the fp16 summands in fp32: half the bytes of the two launches (75 -> 38 MB per head at
+    # 128 crops); every summand is rounded to fp16 once, like every other activation of the mode.  Measured: DESIGN.md 8.6.
+    deconv_cols_f16: bool = True
 
     @property
     def feature_channel(self) -> int:

@@ -340,18 +340,23 @@ __global__ __launch_bounds__(256) void upsample2x_rows_kernel(const T* __restric
 
 // ------------------------------------------------------------------------------------- deconv col2im
 // out[b][y][x][co] = sum over (ky,kx) with y = 2i-1+ky, x = 2j-1+kx of cols[(b,i,j)][(ky*3+kx)*C + co]
-template <typename T>
-__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, T* __restrict__ out, int B,
+// CT = element type of cols: float (the fp32 / split modes), or half_t (round 5, fp16 mode: the deconv GEMM then runs its lean fp16 epilogue and
+// writes half the bytes -- 38 instead of 75 MB per head at 128 crops; each of the up to four summands is rounded to fp16 once, the sum is fp32)
+template <typename T, typename CT>
+__global__ __launch_bounds__(256) void col2im_kernel(const CT* __restrict__ cols, T* __restrict__ out, int B,
                                                      int H, int W, int C) {
-    const int C4 = C / 4, Ho = 2 * H, Wo = 2 * W;
+    constexpr int VEC = 16 / sizeof(CT);
+    const int CV = C / VEC, Ho = 2 * H, Wo = 2 * W;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * Ho * Wo * C4) return;
-    const int c4 = (int)(idx % C4);
-    long t = idx / C4;
+    if (idx >= (long)B * Ho * Wo * CV) return;
+    const int cv = (int)(idx % CV);
+    long t = idx / CV;
     const int ox = (int)(t % Wo); t /= Wo;
     const int oy = (int)(t % Ho);
     const long b = t / Ho;
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = 0.f;
     for (int ky = 0; ky < 3; ++ky) {
         const int ty = oy + 1 - ky;
         if (ty < 0 || (ty & 1)) continue;
@@ -362,12 +367,14 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ c
             if (tx < 0 || (tx & 1)) continue;
             const int j = tx >> 1;
             if (j >= W) continue;
-            a += *reinterpret_cast<const f32x4*>(cols + ((b * H + i) * W + j) * (9L * C) + (ky * 3 + kx) * C + c4 * 4);
+            const Vec16<CT> v = load16<CT>(cols + ((b * H + i) * W + j) * (9L * C) + (ky * 3 + kx) * C + cv * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) a[e] += v.get(e);
         }
     }
-    T* o = out + ((b * Ho + oy) * Wo + ox) * C + c4 * 4;
+    T* o = out + ((b * Ho + oy) * Wo + ox) * C + cv * VEC;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) store_T(o + e, a[e]);
+    for (int e = 0; e < VEC; ++e) store_T(o + e, a[e]);
 }
 
 // ------------------------------------------------------------------------------------- xyz out layer
@@ -947,14 +954,18 @@ extern "C" int gp_pred_rt(const float* R, const float* t, const float* size, con
     GP_LAUNCH_CHECK("gp_pred_rt");
 }
 
-extern "C" int gp_deconv_col2im(const float* cols, void* out, int B, int H, int W, int C, int dtype, void* stream) {
-    GP_REQUIRE(cols && out && B > 0 && C % 4 == 0, "gp_deconv_col2im: bad argument");
+extern "C" int gp_deconv_col2im(const void* cols, void* out, int B, int H, int W, int C, int dtype_in, void* stream) {
+    const int dtype = dtype_in & ~GP_COLS_F16;
+    const bool c16 = (dtype_in & GP_COLS_F16) != 0;
+    GP_REQUIRE(cols && out && B > 0 && C % (c16 ? 8 : 4) == 0, "gp_deconv_col2im: bad argument");
     GP_DT_OK(dtype);
+    GP_REQUIRE(!c16 || dtype == GP_F16, "gp_deconv_col2im: fp16 cols go with fp16 output");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)B * 4 * H * W * (C / 4);
-    gp_timing_before(s, GP_KC_ELEMENTWISE, (double)B * H * W * 9 * C, (double)B * H * W * 9 * C * 4 + (double)total * 4 * (dtype == GP_F16 ? 2 : 4));
-    if (dtype == GP_F16) hipLaunchKernelGGL(col2im_kernel<half_t>, dim3(cdiv(total, 256)), dim3(256), 0, s, cols, (half_t*)out, B, H, W, C);
-    else hipLaunchKernelGGL(col2im_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, cols, (float*)out, B, H, W, C);
+    const long total = (long)B * 4 * H * W * (C / (c16 ? 8 : 4));
+    gp_timing_before(s, GP_KC_ELEMENTWISE, (double)B * H * W * 9 * C, (double)B * H * W * 9 * C * (c16 ? 2 : 4) + (double)B * 4 * H * W * C * (dtype == GP_F16 ? 2 : 4));
+    if (c16) hipLaunchKernelGGL((col2im_kernel<half_t, half_t>), dim3(cdiv(total, 256)), dim3(256), 0, s, (const half_t*)cols, (half_t*)out, B, H, W, C);
+    else if (dtype == GP_F16) hipLaunchKernelGGL((col2im_kernel<half_t, float>), dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)cols, (half_t*)out, B, H, W, C);
+    else hipLaunchKernelGGL((col2im_kernel<float, float>), dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)cols, (float*)out, B, H, W, C);
     GP_LAUNCH_CHECK("gp_deconv_col2im");
 }
 

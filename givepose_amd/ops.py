@@ -476,7 +476,9 @@ def upsample_bilinear2x(x, out, out_planes=False):
 
 
 def deconv_col2im(cols, out, B, H, W_, C):
-    check(_L().gp_deconv_col2im(_ptr(cols), _ptr(out), B, H, W_, C, dtype_code(out.dtype), _stream()), "gp_deconv_col2im")
+    """cols fp32, or (fp16 mode, round 5) fp16 like `out`: GP_COLS_F16."""
+    code = dtype_code(out.dtype) | (0x400 if cols.dtype == torch.float16 else 0)
+    check(_L().gp_deconv_col2im(_ptr(cols), _ptr(out), B, H, W_, C, code, _stream()), "gp_deconv_col2im")
     return out
 
 

@@ -294,7 +294,8 @@ class PoseNet(nn.Module):
             if s > 0:
                 buf[f"dsn{s}"] = e(B, h * 2, h * 2, dims[s - 1])
         # heads
-        buf["cols"] = f(B * 64, 9 * 256)
+        # deconv-as-GEMM output: fp16 in the fp16 mode (round 5: the GEMM's lean epilogue, half the bytes for col2im), fp32 otherwise
+        buf["cols"] = e(B * 64, 9 * 256) if (T == torch.float16 and cfg.deconv_cols_f16 and os.environ.get("GP_DECONV_COLS_F32") != "1") else f(B * 64, 9 * 256)   # (env: A/B switch)
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
         chunks = max(ops.groupnorm_chunks(B, r * r) for r in (8, 16, 32, 64))

@@ -251,8 +251,10 @@ int gp_groupnorm_apply_xyz(const void* x, const float* partial, const float* w, 
 int gp_upsample_bilinear2x(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 /* ConvTranspose2d(k3,s2,p1,op1,bias=False) second half: cols (B*H*W, 9*C) fp32 from gp_gemm with
- * W[(kh*3+kw)*C + co][ci] -> out (B,2H,2W,C) dtype (xyz_head.py:250-259). */
-int gp_deconv_col2im(const float* cols, void* out, int B, int H, int W, int C, int dtype, void* stream);
+ * W[(kh*3+kw)*C + co][ci] -> out (B,2H,2W,C) dtype (xyz_head.py:250-259).  dtype = GP_F16 | GP_COLS_F16 (round 5): cols are fp16
+ * (the GEMM's lean fp16 epilogue: half the bytes; every summand rounded to fp16 once, summed in fp32; C % 8 == 0). */
+#define GP_COLS_F16 0x400
+int gp_deconv_col2im(const void* cols, void* out, int B, int H, int W, int C, int dtype, void* stream);
 
 /* xyz out layer: Conv2d(C,3,1)+bias (xyz_head.py:317-324).  Writes the reference-layout NCHW fp32 map
  * (B,3,HW) and a channels-last (B*HW, 4) fp32 copy (x,y,z,0) for the next consumer. */

@@ -690,6 +690,13 @@ def test_upsample_and_col2im(dt):
     out = torch.empty(B, 2 * H, 2 * H, C, dtype=dt, device="cuda")
     o.deconv_col2im(cols, out, B, H, H, C)
     assert rel_err(out, ref) < TOL[dt]
+    if dt == torch.float16:      # round 5 (PoseNetConfig.deconv_cols_f16): fp16 column matrix, summed in fp32 by the col2im (GP_COLS_F16)
+        cols16 = torch.empty(B * H * H, 9 * C, dtype=dt, device="cuda")
+        o.gemm(xi.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to("cuda", dt), wt.permute(2, 3, 1, 0).reshape(9 * C, Cin).contiguous().to("cuda", dt), cols16)
+        out16 = torch.full_like(out, 7.0)
+        o.deconv_col2im(cols16, out16, B, H, H, C)
+        assert rel_err(out16, ref) < TOL[dt]
+        assert rel_err(out16, out.float().cpu()) < 2e-3
 
 
 @pytest.mark.parametrize("B,H,W,C", [(3, 16, 16, 256), (2, 32, 32, 256), (2, 8, 24, 128), (1, 5, 7, 64)])
