@@ -498,7 +498,11 @@ def main():
                             # (investigation build, scripts/kernel_clock.py) read 1.63-1.83 GHz; the fp16 MFMA rate AT THAT CLOCK is what the
                             # matrix pipe can deliver, and `frac_at_held_clock` prices the class against it (peak stays the guide's 2.5 PFLOP/s)
                             "held_clock": {"ghz_in_kernel": [1.63, 1.83], "source": "profiles/r05_kernel_clock.txt", "peak_at_held_clock": [round(peak * 1.63 / 2.4), round(peak * 1.83 / 2.4)],
-                                           "frac_at_held_clock": [round(g["tflops"] / (peak * 1.83 / 2.4), 3), round(g["tflops"] / (peak * 1.63 / 2.4), 3)]} if args.dtype != "f32" else None}
+                                           "frac_at_held_clock": [round(g["tflops"] / (peak * 1.83 / 2.4), 3), round(g["tflops"] / (peak * 1.63 / 2.4), 3)],
+                                           # a BARE MFMA loop (operands in registers, no LDS, no memory, pipes 99 % busy) on random operands: 1 830 TFLOP/s at 1.81 GHz
+                                           # (2 430-2 470 on zeros at 2.38 GHz): the ceiling of any fp16 MFMA kernel on real data on this chip
+                                           "bare_mfma_loop_random_data_tflops": 1830.0, "bare_mfma_loop_source": "profiles/r05_mfma_peak_bare_loop.txt",
+                                           "frac_of_bare_mfma_loop": round(g["tflops"] / 1830.0, 3)} if args.dtype != "f32" else None}
         if "dcnv3" in classes:
             d = classes["dcnv3"]
             line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
@@ -671,6 +675,7 @@ def main():
             "n_ranks_seen": n_ranks_seen, "ms_per_step": line["ms_per_step"], "dtype": line["dtype"],
             "one_batch_in_flight_bs64_serial": g("one_batch_in_flight", "value"), "one_launch_in_flight": g("one_launch_in_flight", "value"),
             "roofline_frac_gemm_class": g("roofline", "frac"), "roofline_frac_at_held_clock": (g("roofline", "held_clock") or {}).get("frac_at_held_clock"),
+            "roofline_frac_of_bare_mfma_loop_on_random_data": (g("roofline", "held_clock") or {}).get("frac_of_bare_mfma_loop"),
             "timed_mode_vs_oracle_rot_median_worst": [g("vs_reference", "rot_median_over_crops"), g("vs_reference", "rot")],
             "parity_mode_images_per_s": g("parity_mode", "value"), "parity_mode_vs_oracle_rot_trans_size": [(g("parity_mode", "vs_reference") or {}).get(k) for k in ("rot", "trans", "size")],
             "parity_mode_vs_float64_rot": (vf.get("parity_mode") or {}).get("rot"), "fp32_oracle_vs_float64_rot": (vf.get("reference_fp32_cpu") or {}).get("rot"),
