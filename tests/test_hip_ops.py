@@ -308,6 +308,50 @@ def test_gemm_weights_in_registers_variant(variant):
             o.gemm(x, w, torch.zeros(64, 260, dtype=dt, device="cuda"), variant=17, ldc=260, splitk=1)
 
 
+@pytest.mark.parametrize("variant", [19, 20, 21, 22])
+def test_gemm_weights_in_registers_two_accumulator_sets(variant):
+    """Variants 19-22 (round 5, gemm_wreg3_kernel: two accumulator sets, the first MFMA of every accumulator takes the bias as its C operand; 22 / 21 on 16x16x32 MFMAs,
+    19 / 20 on 32x32x16; 21 -- the default of stage-2 fc1 -- and 20 apply the GELU on packed fp16).  22 is variant 17's arithmetic: bit-identical to it, every epilogue, even
+    and odd tile counts per row group (T = 1, 2, 3, 5, 16: both accumulator sets, the peeled last tile), repeated launches.  19 differs by the K order inside an MFMA only
+    (fp32 formula, TOL).  20 / 21: the packed GELU's absolute error (one fp16 rounding of a value in [0.25, 0.5), 2.2e-3 at most for |x| > 4) against the fp32 formula, equal to
+    each other bit for bit only per MFMA shape; the other epilogues run the fp32 activation (= 19 / 22)."""
+    o = ops()
+    dt, K = torch.float16, 512
+    for (M, N, epi) in [(16384, 2048, o.EPI_GELU), (8192, 512, o.EPI_GELU), (4096, 256, o.EPI_NONE), (2048, 1024, o.EPI_LRELU), (1024, 256, o.EPI_RELU),
+                        (24576, 256, o.EPI_GELU), (40960, 256, o.EPI_GELU), (32, 256, o.EPI_GELU), (64, 256, o.EPI_GELU), (160, 512, o.EPI_GELU)]:
+        x, w, b = rnd(M, K, seed=191).to("cuda", dt), rnd(N, K, seed=192, scale=K ** -0.5).to("cuda", dt), rnd(N, seed=193).cuda()
+        ref17 = torch.empty(M, N, dtype=dt, device="cuda")
+        o.gemm(x, w, ref17, bias=b, epilogue=epi, variant=17, splitk=1)
+        lin = x.float() @ w.float().t() + b
+        ref = {o.EPI_NONE: lin, o.EPI_GELU: F.gelu(lin), o.EPI_RELU: F.relu(lin), o.EPI_LRELU: F.leaky_relu(lin, 0.1)}[epi]
+        outs = []
+        for _ in range(3):
+            out = torch.full((M, N), 7.0, dtype=dt, device="cuda")
+            o.gemm(x, w, out, bias=b, epilogue=epi, variant=variant, splitk=1)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, epi)
+        packed = variant in (20, 21) and epi == o.EPI_GELU
+        if variant == 22 or (variant == 21 and epi != o.EPI_GELU):
+            assert torch.equal(outs[0], ref17), (M, N, epi)
+        d = (outs[0].float() - ref).abs()
+        assert float(d.max()) < (3.5e-3 if packed else 2.5e-3) * max(1.0, float(ref.abs().max()) / 4), (M, N, epi, float(d.max()))
+        assert float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) < (5e-4 if packed else 3e-4), (M, N, epi)      # measured 3.7e-4 / 2.1e-4 (fp16 storage: 2^-11 / sqrt 3)
+    # ldc > N, no bias, ragged M (tiles of unequal groups), zero padding columns untouched
+    for (M, N, epi, bias) in [(96, 256, o.EPI_NONE, False), (4096 + 32, 768, o.EPI_GELU, True), (33 * 32, 256, o.EPI_RELU, True)]:
+        x, w = q(rnd(M, K, seed=194), dt), q(rnd(N, K, seed=195, scale=K ** -0.5), dt)
+        b = rnd(N, seed=196) if bias else None
+        lin = x @ w.t() + (b if bias else 0.0)
+        ref = {o.EPI_NONE: lin, o.EPI_GELU: F.gelu(lin), o.EPI_RELU: F.relu(lin)}[epi]
+        out = torch.zeros(M, N + 8, dtype=dt, device="cuda")
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda() if bias else None, epilogue=epi, variant=variant, ldc=N + 8, splitk=1)
+        assert rel_err(out[:, :N], ref) < TOL[dt], (M, N, epi)
+        assert float(out[:, N:].abs().max()) == 0.0
+    x, w = rnd(64, 512, seed=197).to("cuda", dt), rnd(256, 512, seed=198).to("cuda", dt)
+    for bad in (dict(x=x[:48], w=w), dict(x=x, w=w[:192]), dict(x=rnd(64, 256, seed=197).to("cuda", dt), w=rnd(256, 256, seed=198).to("cuda", dt))):
+        with pytest.raises(RuntimeError, match="variant 19-22"):
+            o.gemm(bad["x"], bad["w"], torch.empty(bad["x"].shape[0], bad["w"].shape[0], dtype=dt, device="cuda"), variant=variant, splitk=1)
+
+
 def test_gemm_prefetch_hint_changes_nothing():
     """gp_gemm_desc.prefetch is a hint: the workgroups touch the given bytes (any length, 16-byte pieces, at most four
     1-KB pieces per wave) and the result is bitwise the one without it -- every schedule family, conv and window conv."""
