@@ -25,9 +25,9 @@ def test_spawn_ranks_propagates_failure(tmp_path, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("ranks,extra", [(2, ["--no-roofline"]), (4, [])])
+@pytest.mark.parametrize("ranks,extra", [(2, ["--no-roofline"]), (4, ["--no-serial"])])
 def test_bench_ranks_without_torchrun(ranks, extra):
-    """2 ranks, and 4 ranks WITH the roofline leg (which every rank of an N > 1 run executes, so that none waits in the final barrier
+    """2 ranks (with the serial legs), and 4 ranks WITH the roofline leg (which every rank of an N > 1 run executes, so that none waits in the final barrier
     while rank 0 measures): the 4- / 8-rank control flow of the driver's scaling run, rehearsed on gloo with every rank on cuda:0
     (at most 6 processes may use the card: 4 ranks + this one)."""
     import multiprocessing as mp
@@ -48,8 +48,9 @@ def test_bench_ranks_without_torchrun(ranks, extra):
     assert oc["slots"] == 2 and oc["ranks"] == ranks and oc["batches_per_launch"] == 2 and oc["poses_bitwise_equal_to_serial_replay"] is True
     assert line["config"]["batches_in_flight"] == 4
     assert list(line)[-1] == "summary" and line["summary"]["value"] == line["value"] and line["summary"]["n_ranks_seen"] == ranks
-    assert line["summary"]["one_batch_in_flight_bs64_serial"] > 0 and line["summary"]["one_launch_in_flight"] > 0
-    if not extra:
+    if "--no-serial" not in extra:      # (the serial legs are the 2-rank case's; the 4-rank case runs the roofline leg on every rank instead: 100 -> ~50 s)
+        assert line["summary"]["one_batch_in_flight_bs64_serial"] > 0 and line["summary"]["one_launch_in_flight"] > 0
+    if "--no-roofline" not in extra:
         assert line["roofline"]["frac"] > 0 and "not the N-rank step" in line["roofline"]["measured_on"]
 
 
