@@ -45,6 +45,10 @@ class PoseNetConfig:
     # epilogue) instead of fp32, and gp_deconv_col2im sums the fp16 summands in fp32: half the bytes of the two launches (75 -> 38 MB per head at
     # 128 crops); every summand is rounded to fp16 once, like every other activation of the mode.  Measured: DESIGN.md 8.6.
     deconv_cols_f16: bool = True
+    # build-side switch (fp16 storage only, round 5): stage 2 (C = 512) runs fc1 -> GELU -> fc2 as ONE launch (convnext_mlp512_kernel) from 128 crops per launch up:
+    # the 134 MB hidden tensor never exists (7.2 GB of HBM traffic per 128 crops), but the kernel alone is 8 % slower than the two launches (one wave per SIMD);
+    # end to end: DESIGN.md 8.5.  Off by default.
+    fuse_mlp512: bool = False
 
     @property
     def feature_channel(self) -> int:

@@ -181,7 +181,8 @@ class PoseNet(nn.Module):
                 W[q + "fc1_w"], W[q + "fc1_b"] = gw(g(p + "mlp.fc1.weight")), f32(g(p + "mlp.fc1.bias"))
                 W[q + "fc2_w"], W[q + "fc2_b"] = gw(g(p + "mlp.fc2.weight")), f32(g(p + "mlp.fc2.bias"))
                 W[q + "gamma"] = f32(g(p + "gamma"))
-                if T == torch.float16 and d in (128, 256) and cfg.fuse_mlp:   # fused fc1->GELU->fc2 (csrc/mlp.hip)
+                fuse512 = d == 512 and (cfg.fuse_mlp512 or os.environ.get("GP_FUSE_MLP512") == "1")      # (env: A/B switch)
+                if T == torch.float16 and (d in (128, 256) or fuse512) and cfg.fuse_mlp:   # fused fc1->GELU->fc2 (csrc/mlp.hip)
                     W[q + "fc2_wp"] = ops.convnext_mlp_pack_w2(W[q + "fc2_w"])
                 if T == torch.float16 and d == 512 and cfg.defer_ln:   # LayerNorm folded into fc1's epilogue
                     w1, lw, lb = g(p + "mlp.fc1.weight"), g(p + "norm.weight"), g(p + "norm.bias")
@@ -429,7 +430,7 @@ class PoseNet(nn.Module):
                              gamma=W[q + "gamma"], residual=x2d)
                     continue
                 t = ops.dwconv_ln(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"t{s}"], 7, out_planes=self.split_gemm)
-                if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0 and B >= cfg.fuse_mlp_min_batch:
+                if (q + "fc2_wp") in W and x2d.shape[0] % 256 == 0 and B >= cfg.fuse_mlp_min_batch and (d != 512 or x2d.shape[0] >= 32768):
                     ops.convnext_mlp(t.view(-1, d), W[q + "fc1_w"], W[q + "fc1_b"], W[q + "fc2_wp"], W[q + "fc2_b"],
                                      W[q + "gamma"], x2d, x2d)
                     continue
