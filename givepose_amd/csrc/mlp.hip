@@ -517,233 +517,6 @@ __global__ __launch_bounds__(256) void convnext_mlp512_kernel(const MlpKP p) {
     }
 }
 
-// The same kernel on v_mfma_f32_32x32x16_f16 (round 5, GP_MLP512_S32): a lone wave per SIMD is where the larger MFMA pays -- it hides 5-6 instructions behind
-// each MFMA where a 16x16x32 hides one or two (profiles/r05_mfma_valu_coissue.txt) -- at ~10 % of clock.  Layouts: GEMM1 block = 32 hidden units x 32 rows, A = W1 rows (units)
-// from LDS, B = x rows (lane l: row l % 32, k = 16 ks + 8 (l / 32) .. + 8); accumulator register r of lane (j = l % 32, h = l / 32) is unit 8 (r / 4) + 4 h + r % 4 of row j.  GEMM2 per
-// block of 32 output channels: A = W2p rows (channels), K = the chunk's 32 units in two steps of 16; the B fragment of step s is the lane's OWN GELU output, registers 8 s .. 8 s + 7
-// (k-slot 8 h + t of step s <-> unit 8 (2 s + t / 4) + 4 h + t % 4): gp_convnext_mlp_pack_w2 orders W2's columns accordingly (mlp_pack_w2_s32_kernel).
-typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void convnext_mlp512_s32_kernel(const MlpKP p) {
-    constexpr int C = 512, HD = 2048, NCH = HD / 32, KS = C / 16, NB2 = C / 32, NW = 4;
-    constexpr int ROWB = C * 2, PIECE = 32768, NP = 4, LEAD = 3, NPIECES = 2 * NCH, IPW = PIECE / 1024 / NW;
-    constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
-    constexpr int RING = NP * PIECE, SMEM = (RING + HD * 4) > NW * SLAB ? (RING + HD * 4) : NW * SLAB;
-    static_assert(SMEM <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * 128 + wave * 32;
-
-    float* b1s = reinterpret_cast<float*>(smem + RING);
-    for (int i = tid; i < HD / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
-
-    uint4 xf[KS];      // B fragments of the wave's 32 x rows: lane (j, h) holds x[m0 + j][16 ks + 8 h .. + 8]
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const uint4*>(p.X + (m0 + j) * C + ks * 16 + h * 8);
-
-    // DMA sources and the piece stream: as convnext_mlp512_kernel (same LDS images)
-    const unsigned w1off = (unsigned)(wave * ROWB + ((lane ^ wave) << 4));
-    const int lr = lane >> 2;
-    const unsigned w2off = (unsigned)(((wave * 16 + lr) * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3)) * 2);
-    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
-    auto stage_instr = [&](int q, int i) {
-        const unsigned d = lds0 + (q & (NP - 1)) * PIECE + wave * 1024 + i * NW * 1024;
-        const bool is_w1 = q == 0 || ((q & 1) && q != NPIECES - 1);
-        if (is_w1) {
-            const int ch = (q + 1) >> 1;
-            glds16_sb(reinterpret_cast<const char*>(p.W1) + (long)ch * 32 * ROWB + i * NW * ROWB, w1off ^ (unsigned)((4 * (i & 3)) << 4), d);
-        } else {
-            const int ch = q == NPIECES - 1 ? NCH - 1 : (q >> 1) - 1;
-            glds16_sb(reinterpret_cast<const char*>(p.W2p) + (long)ch * 64 + (long)i * NW * 16 * HD * 2, w2off, d);
-        }
-    };
-    auto mid = [&](int q) {
-        if (q + 1 >= NPIECES) return;
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + 2 < NPIECES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    struct Refill { const char* base; long stride; unsigned voff, xm, dst; };
-    auto refill_of = [&](int qq) {
-        const bool is_w1 = qq == 0 || ((qq & 1) && qq != NPIECES - 1);
-        const int ch = is_w1 ? (qq + 1) >> 1 : (qq == NPIECES - 1 ? NCH - 1 : (qq >> 1) - 1);
-        Refill r;
-        r.base = is_w1 ? reinterpret_cast<const char*>(p.W1) + (long)ch * 32 * ROWB : reinterpret_cast<const char*>(p.W2p) + (long)ch * 64;
-        r.stride = is_w1 ? (long)NW * ROWB : (long)NW * 16 * HD * 2;
-        r.voff = is_w1 ? w1off : w2off;
-        r.xm = is_w1 ? ~0u : 0u;
-        r.dst = lds0 + (qq & (NP - 1)) * PIECE + wave * 1024;
-        return r;
-    };
-    auto refill = [&](const Refill& r, int i) { glds16_sb(r.base + i * r.stride, r.voff ^ ((unsigned)((4 * (i & 3)) << 4) & r.xm), r.dst + i * NW * 1024); };
-
-    // output accumulators: block nb (32 channels), register r: channel 32 nb + 8 (r / 4) + 4 h + r % 4 of row j; the bias as the initial value
-    mlp_f32x16 acc2[NB2];
-#pragma unroll
-    for (int nb = 0; nb < NB2; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + nb * 32 + g * 8 + h * 4);
-            acc2[nb][4 * g] = b[0]; acc2[nb][4 * g + 1] = b[1]; acc2[nb][4 * g + 2] = b[2]; acc2[nb][4 * g + 3] = b[3];
-        }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < LEAD; ++q)
-#pragma unroll
-        for (int i = 0; i < IPW; ++i) stage_instr(q, i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // W1 fragment ks of a piece: unit j, logical 16-byte chunk 2 ks + h at position chunk ^ (j & 15): byte j * 1024 + (ks / 8) * 256 + (((2 (ks % 8) | h) ^ (j & 15)) << 4)
-    unsigned w1fo[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) w1fo[q] = j * ROWB + ((((2 * q) | h) ^ (j & 15)) << 4);
-    // W2 fragment (nb, s): channel 32 nb + j, chunk 2 s + h of the row's four, at position chunk ^ swz(row % 16)
-    unsigned w2fo[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) w2fo[s2] = j * 64 + ((((2 * s2) | h) ^ ((-((j & 15) >> 2)) & 3)) << 4);
-
-    mlp_f32x16 acc1;             // the hidden accumulators of the chunk GEMM1 is working on
-    unsigned xq[8], hw[8];       // previous chunk: values rounded to packed fp16 (pair c = registers 2 c, 2 c + 1) / their GELU
-    half2v hx[2], hu[2], hp[2];
-
-    auto gemm1 = [&](int ch, int q, auto shc, auto rf1c, auto rf2c) {
-        constexpr bool RF1 = decltype(rf1c)::value, RF2 = decltype(rf2c)::value, SH = decltype(shc)::value;
-        const int slot = q & (NP - 1);
-        const Refill rp1 = refill_of(RF1 ? q + 2 : 0), rp2 = refill_of(RF2 ? q + 3 : 0);
-        constexpr int NSL = GELU16_SLICES - 1, NCALL = 8 * NSL, NMF = KS;
-        const char* s1 = smem + slot * PIECE;
-        uint4 a1[4];
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) a1[ks] = *reinterpret_cast<const uint4*>(s1 + w1fo[ks & 7] + (ks >> 3) * 256);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + ch * 32 + g * 8 + h * 4);
-            acc1[4 * g] = b[0]; acc1[4 * g + 1] = b[1]; acc1[4 * g + 2] = b[2]; acc1[4 * g + 3] = b[3];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, KS>([&](auto ksc) {
-            constexpr int ks = decltype(ksc)::value, i = ks;
-            if constexpr (ks + 3 < KS) a1[(ks + 3) & 3] = *reinterpret_cast<const uint4*>(s1 + w1fo[(ks + 3) & 7] + ((ks + 3) >> 3) * 256);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (i == NMF / 2) mid(q);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&a1[ks & 3]), *reinterpret_cast<const half8*>(&xf[ks]), acc1, 0, 0, 0);
-            if constexpr (RF1 && i < NMF / 2 && i % (NMF / 2 / IPW) == 0) refill(rp1, i / (NMF / 2 / IPW));
-            if constexpr (RF2 && i >= NMF / 2 && (i - NMF / 2) % (NMF / 2 / IPW) == 0) refill(rp2, (i - NMF / 2) / (NMF / 2 / IPW));
-            if constexpr (SH) {
-                constexpr int n0 = i * NCALL / NMF, n1 = (i + 1) * NCALL / NMF;
-                static_for<n0, n1>([&](auto nc) {
-                    constexpr int n = decltype(nc)::value, g = n / (2 * NSL), m = n % (2 * NSL), slot_ = m / 2 + 1, chn = m % 2, c = 2 * g + chn;
-                    if constexpr (slot_ == 1) hx[chn] = __builtin_bit_cast(half2v, xq[c]);
-                    gelu16_slice<slot_>(f32x2{0.f, 0.f}, hx[chn], hu[chn], hp[chn]);
-                    if constexpr (slot_ == GELU16_SLICES - 1) hw[c] = __builtin_bit_cast(unsigned, hp[chn]);
-                });
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        static_for<0, 8>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            xq[c] = __builtin_bit_cast(unsigned, half2v{(half_t)acc1[2 * c], (half_t)acc1[2 * c + 1]});
-        });
-    };
-    auto gelu_plain = [&]() {
-        static_for<0, 8>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            half2v xh = __builtin_bit_cast(half2v, xq[c]), u, pp;
-            static_for<1, GELU16_SLICES>([&](auto sc) { gelu16_slice<decltype(sc)::value>(f32x2{0.f, 0.f}, xh, u, pp); });
-            hw[c] = __builtin_bit_cast(unsigned, pp);
-        });
-    };
-    auto gemm2 = [&](int q) {
-        const int slot = q & (NP - 1);
-        const char* s2 = smem + slot * PIECE;
-        const uint4 hb0 = uint4{hw[0], hw[1], hw[2], hw[3]}, hb1 = uint4{hw[4], hw[5], hw[6], hw[7]};
-        uint4 a2[4];     // fragments (nb, s) in the order 2 nb + s
-#pragma unroll
-        for (int f = 0; f < 3; ++f) a2[f] = *reinterpret_cast<const uint4*>(s2 + (f >> 1) * 2048 + w2fo[f & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 2 * NB2>([&](auto fc) {
-            constexpr int f = decltype(fc)::value, nb = f / 2, s_ = f % 2;
-            if constexpr (f + 3 < 2 * NB2) a2[(f + 3) & 3] = *reinterpret_cast<const uint4*>(s2 + ((f + 3) >> 1) * 2048 + w2fo[(f + 3) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (f == NB2) mid(q);
-            acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&a2[f & 3]), *reinterpret_cast<const half8*>(s_ ? &hb1 : &hb0), acc2[nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-#ifdef GP_MLP_STAMPS
-    unsigned long long tg1 = 0, tg2 = 0, tt0 = __builtin_amdgcn_s_memtime(), ta, tb;
-#define GP_MS(x) x
-#else
-#define GP_MS(x)
-#endif
-    gemm1(0, 0, F_{}, F_{}, F_{});
-    for (int c = 0; c + 2 < NCH; ++c) {
-        GP_MS(ta = __builtin_amdgcn_s_memtime();)
-        gemm1(c + 1, 2 * c + 1, T_{}, T_{}, T_{});
-        GP_MS(tb = __builtin_amdgcn_s_memtime(); tg1 += tb - ta;)
-        gemm2(2 * c + 2);
-        GP_MS(ta = __builtin_amdgcn_s_memtime(); tg2 += ta - tb;)
-    }
-    gemm1(NCH - 1, NPIECES - 3, T_{}, T_{}, F_{});
-    gemm2(NPIECES - 2);
-    gelu_plain();
-    gemm2(NPIECES - 1);
-    GP_MS(const unsigned long long tt1 = __builtin_amdgcn_s_memtime();)
-    __syncthreads();   // every wave is done with the ring: the slabs overlay it
-
-    // ---- epilogue: gamma in the MFMA layout, fp16, transpose through a wave-private LDS slab, + residual, 1 KB rows stored 16 B per lane
-    char* slab = smem + wave * SLAB;
-#pragma unroll
-    for (int nb = 0; nb < NB2; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = nb * 32 + g * 8 + h * 4;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
-            half4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (half_t)(acc2[nb][4 * g + e] * gm[e]);
-            *reinterpret_cast<half4*>(slab + j * PITCH + n * 2) = o;
-        }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-        half8 rres[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i0 + i) * C + lane * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            half8 v = *reinterpret_cast<const half8*>(slab + (i0 + i) * PITCH + lane * 16);
-            v += rres[i];
-            *reinterpret_cast<half8*>(p.out + (m0 + i0 + i) * C + lane * 8) = v;
-        }
-    }
-#ifdef GP_MLP_STAMPS
-    // investigation build: the wave's cycle counts (loop GEMM1 phases, loop GEMM2 phases, main loop, whole kernel) over the first 32 bytes of its first output row
-    const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.out + m0 * C);
-        o[0] = tg1; o[1] = tg2; o[2] = tt1 - tt0; o[3] = tt2 - tt0;
-    }
-#endif
-}
-
-// C = 512, 32x32x16 kernel: inside every block of 32 hidden units, k-position 16 s + 8 h + t takes unit 16 s + 8 (t / 4) + 4 h + t % 4
-__global__ void mlp_pack_w2_s32_kernel(const half_t* w2, half_t* w2p, int C, int HD) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)C * HD) return;
-    const int c = (int)(i / HD), pos = (int)(i - (long)c * HD);
-    const int blk = pos >> 5, t32 = pos & 31, s = t32 >> 4, hh = (t32 >> 3) & 1, t = t32 & 7;
-    w2p[i] = w2[(long)c * HD + blk * 32 + 16 * s + 8 * (t >> 2) + 4 * hh + (t & 3)];
-}
-
 // W2 (C, 4C) -> W2p: inside every block of 32 hidden units, k-slot s = fq*8 + nt*4 + j takes unit nt*16 + fq*4 + j
 __global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -755,20 +528,10 @@ __global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD)
 
 }  // namespace
 
-// GP_MLP512_S32=1: the C = 512 kernel on 32x32x16 MFMAs (its own W2p column order: pack and launch read the same switch, once per process)
-static bool mlp512_s32() {
-    static const bool on = [] { const char* e = getenv("GP_MLP512_S32"); return e && e[0] == '1'; }();
-    return on;
-}
-
 extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream) {
     GP_REQUIRE(w2 && w2p && w2 != w2p, "gp_convnext_mlp_pack_w2: bad pointers");
     GP_REQUIRE(C == 128 || C == 256 || C == 512, "gp_convnext_mlp_pack_w2: C=%d must be 128, 256 or 512", C);
     const long n = (long)C * 4 * C;
-    if (C == 512 && mlp512_s32())
-        hipLaunchKernelGGL(mlp_pack_w2_s32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const half_t*>(w2), reinterpret_cast<half_t*>(w2p), C, 4 * C);
-    else
     hipLaunchKernelGGL(mlp_pack_w2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const half_t*>(w2), reinterpret_cast<half_t*>(w2p), C, 4 * C);
     hipError_t e = hipGetLastError();
@@ -798,8 +561,7 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
     if (C == 512) {
         const dim3 grid512((unsigned)(M / 128));
         GP_REQUIRE(gp_gelu16_enabled(), "gp_convnext_mlp: the C = 512 kernel exists with the packed-fp16 GELU only (GP_GELU16=0: run fc1 / fc2 through gp_gemm)");
-        if (mlp512_s32()) hipLaunchKernelGGL(convnext_mlp512_s32_kernel, grid512, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(convnext_mlp512_kernel, grid512, dim3(256), 0, s, p);
+        hipLaunchKernelGGL(convnext_mlp512_kernel, grid512, dim3(256), 0, s, p);
         GP_LAUNCH_CHECK("gp_convnext_mlp");
     }
     const dim3 grid((unsigned)(M / 256));
