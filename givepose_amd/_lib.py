@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
-ABI_VERSION = 320        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
+ABI_VERSION = 321        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
 GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
@@ -31,7 +31,7 @@ class GemmDesc(Structure):
                 ("co_scheduled", c_int), ("prefetch", c_void_p), ("prefetch_bytes", c_long),
                 ("split_shift", c_int), ("x_plane_stride", c_long), ("w_plane_stride", c_long),
                 ("out_planes", c_int), ("c_plane_stride", c_long),
-                ("residual_f32", c_int), ("c16", c_void_p), ("ldc16", c_int)]
+                ("residual_f32", c_int), ("c16", c_void_p), ("ldc16", c_int), ("gn_rows", c_int)]
 
 
 # name -> argtypes; every symbol include/givepose_hip.h declares (tests/test_abi.py checks both ways)
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "gp_dcnv3_forward_any": ([_P] * 4 + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_dcnv3_backward": ([_P] * 7 + [c_long, c_long] + [c_int] * 13 + [c_float] + [c_int] * 3 + [_P], c_int),
     "gp_gemm": ([POINTER(GemmDesc), _P], c_int),
+    "gp_gemm_gn_rows": ([c_int] * 4, c_int),
     "gp_split_planes": ([_P, _P, c_long, c_int, c_long, c_long, c_int, _P], c_int),
     "gp_convnext_mlp_pack_w2": ([_P, _P, c_int, _P], c_int),
     "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),

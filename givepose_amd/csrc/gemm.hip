@@ -1909,7 +1909,7 @@ __device__ __forceinline__ half8 to_mfma_lanes(half8 v, int pull) {
 
 template <int MT, int NT, int KCH, bool CONV, bool GN>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
-    static_assert(!GN || (MT == 4 && NT == 2), "fused GroupNorm statistics: one workgroup = one 64-row chunk x 32 columns");
+    static_assert(!GN || NT == 2, "fused GroupNorm statistics: one workgroup = one (16 MT)-row chunk x 32 columns");
     extern __shared__ __attribute__((aligned(16))) char smallm_lds[];           // 4 waves x MT NT tiles x 64 lanes x 16 B (<= 32 KB)
     f32x4 (*red)[MT * NT][64] = reinterpret_cast<f32x4 (*)[MT * NT][64]>(smallm_lds);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;     // (wave stays a vector value: the conv's tap state in SGPRs spilled them)
@@ -2045,22 +2045,29 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
     }
     if constexpr (GN) {
         __shared__ float gred[4][4][2];
-        // fused GroupNorm statistics: (sum, sum of squares) of this 64-row chunk per channel group, in the tile kernels' layout
-        // (B, HW / 64, G, 2).  Wave w finished m-tiles w / 2 and w / 2 + 2 of n-tile w % 2: 16 rows by shuffle, the group's second
-        // 4-column quad (8 channels per group) by shuffle, the two waves of an n-tile through LDS in fixed order.
+        // fused GroupNorm statistics: (sum, sum of squares) of this (16 MT)-row chunk per channel group, in the tile kernels' layout
+        // (B, HW / (16 MT), G, 2) (gp_gemm_desc.gn_rows = 16 MT: 64 as the tile kernels, or -- round 5 -- 32 / 16 where few rows want more
+        // workgroups and fewer load rounds).  Wave w finished the m-tiles w / 2 (+ 2) of n-tile w % 2 (MT = 1: waves 0 and 1 only): 16 rows by
+        // shuffle, the group's second 4-column quad (8 channels per group) by shuffle, the waves of an n-tile through LDS in fixed order.
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { gs += __shfl_xor(gs, o, 64); gq += __shfl_xor(gq, o, 64); }
         if (p.gn_cpg == 8) { gs += __shfl_xor(gs, 16, 64); gq += __shfl_xor(gq, 16, 64); }
-        if (r == 0) { gred[wave][q][0] = gs; gred[wave][q][1] = gq; }
+        if (r == 0) { gred[wave][q][0] = gs; gred[wave][q][1] = gq; }     // (a wave without a tile -- MT = 1: waves 2, 3 -- writes zeros, never read)
         __syncthreads();
         if (threadIdx.x < 8) {
             const int nt = threadIdx.x >> 2, qq = threadIdx.x & 3;
             if (p.gn_cpg == 4 || (qq & 1) == 0) {
-                const int G = p.N / p.gn_cpg, cpi = p.gn_hw >> 6;
-                const int b = m0 / p.gn_hw, ch = (m0 - b * p.gn_hw) >> 6;
+                constexpr int ROWS = 16 * MT;
+                const int G = p.N / p.gn_cpg, cpi = p.gn_hw / ROWS;
+                const int b = m0 / p.gn_hw, ch = (m0 - b * p.gn_hw) / ROWS;
                 float* o = p.gn_partial + (((long)b * cpi + ch) * G + (n0 + nt * 16 + qq * 4) / p.gn_cpg) * 2;
-                o[0] = gred[nt][qq][0] + gred[nt + 2][qq][0];
-                o[1] = gred[nt][qq][1] + gred[nt + 2][qq][1];
+                if constexpr (MT == 1) {
+                    o[0] = gred[nt][qq][0];
+                    o[1] = gred[nt][qq][1];
+                } else {
+                    o[0] = gred[nt][qq][0] + gred[nt + 2][qq][0];
+                    o[1] = gred[nt][qq][1] + gred[nt + 2][qq][1];
+                }
             }
         }
     }
@@ -2070,7 +2077,8 @@ template <int MT, int NT, bool CONV, bool GN>
 static void launch_smallm(const GemmKP& p, hipStream_t s) {
     // fragments in flight: (MT + NT) x KCH x 4 registers <= 256 (one wave per SIMD); convs: 9 (3 x 3 x Cin / 128 steps per wave come
     // in nines, and 16 unrolled steps of tap state spilled SGPRs); conv + fused GroupNorm statistics: 6 (9 spilled two SGPRs)
-    constexpr int KMAX = (CONV && GN) ? 6 : (CONV || MT + NT > 4) ? 9 : 16;
+    // (MT <= 2 with fused statistics: 9, two rounds for the heads' 3 x 3 x 256 convs where the 64-row tile takes three of 6)
+    constexpr int KMAX = (CONV && GN) ? (MT == 4 ? 6 : 9) : (CONV || MT + NT > 4) ? 9 : 16;
     const int per = (p.K / 32 + 3) / 4, rounds = (per + KMAX - 1) / KMAX, kch = (per + rounds - 1) / rounds;
     const dim3 grid(p.N / (16 * NT), p.M / (16 * MT));
     constexpr int LDS = 4 * MT * NT * 1024;
@@ -2093,6 +2101,84 @@ static void launch_smallm(const GemmKP& p, hipStream_t s) {
     }
     GP_SM(KMAX);
 #undef GP_SM
+}
+
+
+// ============================================================================ row-vector GEMM (variant 23, round 5)
+// M <= 8 rows -- ConvPnPNet's fc1 / fc2 over the detections of one frame (network/conv_pnp_net.py:186-199: M = the number of crops, fc1 is 2048 x 8192 = 32 MB of
+// weights): the 128 x 128 tile kernel spends 14 + 8 us on it (split-K + reduce; one tile row of 128 for 1-8 used rows).  Here a wave owns TWO output columns and
+// streams their weight rows straight into registers, 16 bytes per lane, every load of a 4 096-wide K block issued before anything waits; the few x rows go through
+// LDS once per workgroup (8 columns); v_dot2_f32_f16 into fp32 accumulators per (row, column), a butterfly over the lanes, lane 0 applies bias / activation.
+// One workgroup per 8 columns: 256 for fc1 = one per CU, each pulling 128 KB of weights.  Deterministic (fixed reduction order), fp16 in, fp16 or fp32 out.
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemmKP p) {
+    constexpr int KC = 4096, NCH = KC / 512;
+    __shared__ __attribute__((aligned(16))) half_t xs[MR][KC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 8 + wave * 2;
+    const half_t* X = reinterpret_cast<const half_t*>(p.X);
+    const half_t* W0 = reinterpret_cast<const half_t*>(p.W) + (long)n0 * p.K + lane * 8;
+    float acc[MR][2];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m][0] = acc[m][1] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        const int kc = min(KC, p.K - k0), nch = kc >> 9;          // K % 512 == 0 (host)
+        uint4 w[2][NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (j < nch) {
+                w[0][j] = *reinterpret_cast<const uint4*>(W0 + k0 + j * 512);
+                w[1][j] = *reinterpret_cast<const uint4*>(W0 + p.K + k0 + j * 512);
+            }
+        if (k0) __syncthreads();
+        for (int i = tid; i < MR * (kc >> 3); i += 256) {
+            const int m = i / (kc >> 3), c = i - m * (kc >> 3);
+            uint4 v = uint4{0u, 0u, 0u, 0u};
+            if (m < p.M) v = *reinterpret_cast<const uint4*>(X + (long)m * p.ldx + k0 + c * 8);
+            *reinterpret_cast<uint4*>(&xs[m][c * 8]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (j < nch) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(&xs[m][j * 512 + lane * 8]);
+                    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const unsigned ww[4] = {w[c][j].x, w[c][j].y, w[c][j].z, w[c][j].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[m][c] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, xw[e]), __builtin_bit_cast(half2v, ww[e]), acc[m][c], false);
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc[m][c] += __shfl_xor(acc[m][c], o, 64);
+    if (lane == 0) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            if (m < p.M) {
+                const f32x4 b = p.bias ? f32x4{p.bias[n0], p.bias[n0 + 1], 0.f, 0.f} : z;
+                const f32x4 v = epi_apply<half_t>(p.epi, f32x4{acc[m][0], acc[m][1], 0.f, 0.f}, b, z, half4{0, 0, 0, 0});
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n0;
+                    o[0] = v[0];
+                    o[1] = v[1];
+                } else {
+                    half_t* o = reinterpret_cast<half_t*>(p.C) + (long)m * p.ldc + n0;
+                    o[0] = (half_t)v[0];
+                    o[1] = (half_t)v[1];
+                }
+            }
+    }
 }
 
 }  // namespace
@@ -2153,6 +2239,18 @@ static double smallm_tile_bias() {   // GP_GEMM_SMALLM_BIAS=<us>: added to the t
     static const double b = [] { const char* e = getenv("GP_GEMM_SMALLM_BIAS"); return e ? atof(e) : 0.0; }();
     return b;
 }
+// the latency kernel's cost model (us), see gp_gemm: tile (16 mt) x 32
+static double smallm_estimate(int M, int N, int K, int mt) {
+    const double wgs = (double)(M / (16 * mt)) * (N / 32), kb_per_wg = (16.0 * mt + 32.0) * K * 2.0 / 1024.0;
+    const double one = 1.0 + kb_per_wg / 60.0, many = wgs / 256.0 * kb_per_wg / 45.0;
+    return 2.6 + (one > many ? one : many) + (mt == 4 ? 1.5 : 0.0);
+}
+
+static bool gemv_enabled() {   // GP_GEMM_GEMV=0: A/B switch, keeps the row-vector kernel (variant 23) out of the automatic choice
+    static const bool on = [] { const char* e = getenv("GP_GEMM_GEMV"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool smallm_enabled() {   // GP_GEMM_SMALLM=0: A/B switch, keeps the latency kernel (variant 18) out of the automatic choice
     static const bool on = [] { const char* e = getenv("GP_GEMM_SMALLM"); return !(e && e[0] == '0'); }();
     return on;
@@ -2161,6 +2259,22 @@ static bool smallm_enabled() {   // GP_GEMM_SMALLM=0: A/B switch, keeps the late
 static long pp_min_tiles() {
     const char* e = getenv("GP_GEMM_PP_MIN_TILES");
     return e ? atol(e) : 192;
+}
+
+// Rows per fused-GroupNorm statistics chunk for an fp16 GEMM / conv of this shape (gp_gemm_desc.gn_rows; the consumers take chunks = HW / rows): 64 -- the
+// tile kernels' chunk -- unless the latency kernel would take the launch and a smaller tile is faster by its cost model (few rows: the detections of one
+// frame; 16-row tiles give the heads' 3 x 3 convs at one crop 128 workgroups and two load rounds instead of 32 and three).
+extern "C" int gp_gemm_gn_rows(int M, int N, int K, int hw) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32 || M % 16 || hw % 64 || !smallm_enabled() || M > 32768) return 64;
+    double best = 1e30;
+    int mt_best = 4;
+    for (int mt = 1; mt <= 4; mt *= 2) {
+        if (M % (16 * mt)) continue;
+        const double t = smallm_estimate(M, N, K, mt);
+        if (t < best) { best = t; mt_best = mt; }
+    }
+    if (best > 30.0 + smallm_tile_bias()) return 64;
+    return 16 * mt_best;
 }
 
 extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
@@ -2223,6 +2337,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_REQUIRE(d->gn_groups > 0 && d->N % d->gn_groups == 0 && (d->N / d->gn_groups == 4 || d->N / d->gn_groups == 8),
                    "gp_gemm: fused GroupNorm needs 4 or 8 channels per group");
         GP_REQUIRE(d->gn_hw > 0 && d->gn_hw % 64 == 0 && d->M % d->gn_hw == 0, "gp_gemm: fused GroupNorm needs HW %% 64 == 0");
+        GP_REQUIRE(d->gn_rows == 0 || d->gn_rows == 16 || d->gn_rows == 32 || d->gn_rows == 64, "gp_gemm: gn_rows is 0 (= 64), 16, 32 or 64");
         GP_REQUIRE(d->splitk <= 1, "gp_gemm: fused GroupNorm excludes split-K");
         p.gn_partial = d->gn_partial; p.gn_cpg = d->N / d->gn_groups; p.gn_hw = d->gn_hw;
     }
@@ -2256,7 +2371,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // few rows (the detections of one frame): the latency kernel (variant 18), whatever split-K factor the caller worked out for the
     // tile kernels.  GP_GEMM_SMALLM=0 keeps it out of the automatic choice (A/B switch)
     const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
-                           (!d->gn_partial || (d->M % 64 == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
+                           (!d->gn_partial || (d->M % (d->gn_rows ? d->gn_rows : 64) == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
                            d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
                            ((size_t)d->W & 15) == 0 && ((size_t)d->C & 7) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
                            (!d->gamma || ((size_t)d->gamma & 15) == 0) && (!d->residual || ((size_t)d->residual & 7) == 0);
@@ -2270,25 +2385,39 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // cost ~9 us + K / 160, never more than ~22 -- ~30 with fused GroupNorm statistics (their 128 x 128 tile + statistics epilogue is
     // 32 us flat up to 4 096 rows): the latency kernel takes the launch when its estimate is below that.  Fused GroupNorm
     // statistics need the 64-row tile.
+    // M <= 8 rows of a plain GEMM: the row-vector kernel (variant 23; GP_GEMM_GEMV=0 keeps it out of the automatic choice)
+    const bool gemv_ok = d->dtype == GP_F16 && !split && !r32 && !d->c16 && d->KH == 0 && !d->gn_partial && d->M <= 8 && d->K % 512 == 0 && d->N % 8 == 0 &&
+                         d->ldx % 8 == 0 && d->epilogue <= GP_EPI_LRELU && ((size_t)d->X & 15) == 0 && ((size_t)d->W & 15) == 0 && ((size_t)d->C & 3) == 0 && d->ldc % 2 == 0;
+    if (variant == 23 || (variant == 0 && gemv_ok && gemv_enabled())) {
+        GP_REQUIRE(gemv_ok, "gp_gemm: variant 23 needs a plain fp16 GEMM of M <= 8 rows, K %% 512 == 0, N %% 8 == 0, bias / GELU / ReLU / LeakyReLU epilogue");
+        p.splitk = 1;
+        gp_timing_label("gemm v23 M%d N%d K%d epi%d", d->M, d->N, d->K, d->epilogue);
+        const dim3 grid(d->N / 8);
+        if (d->M <= 1) hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(256), 0, s, p);
+        else if (d->M <= 2) hipLaunchKernelGGL(gemv_kernel<2>, grid, dim3(256), 0, s, p);
+        else if (d->M <= 4) hipLaunchKernelGGL(gemv_kernel<4>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(gemv_kernel<8>, grid, dim3(256), 0, s, p);
+        GP_LAUNCH_CHECK("gp_gemm");
+    }
     int sm_mt = 0;
     // (the estimate below was fitted on 1-8 crops: the automatic choice stops at 32 768 rows -- 16 crops' worth of the widest map it was
     // measured on -- whatever the estimate says beyond; tests/test_hip_posenet.py pins which launches take it at 4 / 8 / 16 crops)
     if (smallm_ok && smallm_enabled() && d->M <= 32768) {
         double best = 1e30;
-        for (int mt = d->gn_partial ? 4 : 1; mt <= 4; mt *= 2) {
+        const int gn_mt = d->gn_partial ? (d->gn_rows ? d->gn_rows / 16 : 4) : 0;      // fused statistics: the caller's chunk rows ARE the tile rows
+        for (int mt = gn_mt ? gn_mt : 1; mt <= (gn_mt ? gn_mt : 4); mt *= 2) {
             if (d->M % (16 * mt)) continue;
-            const double wgs = (double)(d->M / (16 * mt)) * (d->N / 32), kb_per_wg = (16.0 * mt + 32.0) * d->K * 2.0 / 1024.0;
-            const double one = 1.0 + kb_per_wg / 60.0, many = wgs / 256.0 * kb_per_wg / 45.0;
-            const double t = 2.6 + (one > many ? one : many) + (mt == 4 ? 1.5 : 0.0);
+            const double t = smallm_estimate(d->M, d->N, d->K, mt);
             if (t < best) { best = t; sm_mt = mt; }
         }
         const double tile = (d->gn_partial ? 30.0 : 9.0 + d->K / 160.0 < 22.0 ? 9.0 + d->K / 160.0 : 22.0) + smallm_tile_bias();
-        if (best > tile) sm_mt = 0;
+        if (best > tile && !(gn_mt && gn_mt < 4)) sm_mt = 0;      // (statistics chunks of 16 / 32 rows exist in this kernel only: gp_gemm_gn_rows made the choice)
     }
     if ((variant == 0 && sm_mt) || variant == 18) {
         variant = 18;
         p.splitk = 1;
         if (!sm_mt) sm_mt = d->M % 64 == 0 && (d->M >= 2048 || d->gn_partial) ? 4 : d->M % 32 == 0 && d->M > 512 ? 2 : 1;     // explicit request: by row count
+        if (d->gn_partial && d->gn_rows) sm_mt = d->gn_rows / 16;
         // variants 218 / 318 / 418: the tile forced to 16 x 32 / 32 x 32 / 64 x 32 (tests, scripts/small_m_variants.py)
         if (p.dbg >= 2 && p.dbg <= 4 && !d->gn_partial && d->M % (8 << (p.dbg - 1)) == 0) sm_mt = 1 << (p.dbg - 2);
     }
@@ -2324,18 +2453,23 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                         (!d->out_f32 || split) && p.splitk == 1 && d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0 && !d->out_planes &&
                         (d->epilogue == GP_EPI_NONE || d->epilogue == GP_EPI_GELU || d->epilogue == GP_EPI_RELU);
     if (variant == 10 && d->variant % 100 == 0 && win_ok && conv_window_enabled()) variant = 13;
+    GP_REQUIRE(!(d->gn_partial && d->gn_rows && d->gn_rows != 64) || variant == 18, "gp_gemm: gn_rows=%d needs the small-M kernel (variant 18: fp16, N %% 32 == 0, M %% gn_rows == 0), got variant %d", d->gn_rows, variant);
     GP_REQUIRE(((variant >= 2 && variant <= 13 && variant != 6) || (variant >= 16 && variant <= 22)) && (variant == 4 || p.splitk == 1), "gp_gemm: bad variant %d (split-K runs on variant 4)", variant);
     GP_REQUIRE(!split || variant == 4 || variant == 7 || variant == 8 || variant == 10 || variant == 13, "gp_gemm: split-operand mode runs on variants 4 / 7 / 8 / 10 / 13 (got %d)", variant);
     GP_REQUIRE(!r32 || variant == 7 || variant == 10, "gp_gemm: residual_f32 runs on variants 7 / 10 (got %d)", variant);
     // c16 is written by the generic epilogue of gemm_big_kernel only (out_f32 keeps every tile off the lean one); the window conv
     // and the weights-in-registers kernel would return without it
     GP_REQUIRE(!d->c16 || (variant != 13 && variant != 16 && variant != 17 && !split), "gp_gemm: c16 runs on the tile kernels (variants 2-5, 7-12), not on %d%s", variant, split ? " split" : "");
-    if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? " +gn" : "", split ? " split3" : "");
+    if (d->KH > 0) gp_timing_label("conv%dx%d s%d v%d %dx%d Cin%d Cout%d M%d%s%s", d->KH, d->KW, d->stride, variant, d->H, d->Win, d->Cin, d->N, d->M, d->gn_partial ? (d->gn_rows == 16 ? " +gn16" : d->gn_rows == 32 ? " +gn32" : " +gn") : "", split ? " split3" : "");
     else gp_timing_label("gemm v%d M%d N%d K%d epi%d%s%s%s", variant, d->M, d->N, d->K, d->epilogue, p.splitk > 1 ? " splitK" : "", d->gn_partial ? " +gn" : "", split ? " split3" : "");
     if (variant == 18) {
         GP_REQUIRE(smallm_ok, "gp_gemm: variant 18 needs a plain fp16 GEMM / conv (fp16 out, no split-K), N %% 32 == 0, M %% 16 == 0 (%% 64 with fused GroupNorm statistics)");
-        GP_REQUIRE(d->M / (16 * (d->gn_partial ? 4 : sm_mt)) <= 65535, "gp_gemm: variant 18: M=%d gives more than 65535 row tiles (grid.y)", d->M);
-        if (d->gn_partial) { if (d->KH > 0) launch_smallm<4, 2, true, true>(p, s); else launch_smallm<4, 2, false, true>(p, s); }
+        GP_REQUIRE(d->M / (16 * sm_mt) <= 65535, "gp_gemm: variant 18: M=%d gives more than 65535 row tiles (grid.y)", d->M);
+        if (d->gn_partial) {
+            GP_REQUIRE(sm_mt == 1 || sm_mt == 2 || sm_mt == 4, "gp_gemm: variant 18: bad statistics chunk");
+            if (d->KH > 0) { if (sm_mt == 4) launch_smallm<4, 2, true, true>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, true, true>(p, s); else launch_smallm<1, 2, true, true>(p, s); }
+            else { if (sm_mt == 4) launch_smallm<4, 2, false, true>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, false, true>(p, s); else launch_smallm<1, 2, false, true>(p, s); }
+        }
         else if (d->KH > 0) { if (sm_mt == 4) launch_smallm<4, 2, true, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, true, false>(p, s); else launch_smallm<1, 2, true, false>(p, s); }
         else { if (sm_mt == 4) launch_smallm<4, 2, false, false>(p, s); else if (sm_mt == 2) launch_smallm<2, 2, false, false>(p, s); else launch_smallm<1, 2, false, false>(p, s); }
         GP_LAUNCH_CHECK("gp_gemm");

@@ -246,8 +246,9 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
         d.prefetch, d.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     if ln is not None:       # (row moments (M,2,nslab), column sums of w, nslab, eps): EPI_LNFOLD_GELU
         d.ln_stats, d.ln_colsum, d.ln_nslab, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2], ln[3]
-    if gn is not None:       # (partial buffer, groups, pixels per image): fused GroupNorm statistics of the output
+    if gn is not None:       # (partial buffer, groups, pixels per image[, rows per statistics chunk]): fused GroupNorm statistics of the output
         d.gn_partial, d.gn_groups, d.gn_hw = gn[0].data_ptr(), gn[1], gn[2]
+        d.gn_rows = gn[3] if len(gn) > 3 else 0
     check(_L().gp_gemm(ctypes.byref(d), _stream()), "gp_gemm")
     return out
 
@@ -438,33 +439,39 @@ def groupnorm_chunks(B, HW):
     return _L().gp_groupnorm_chunks(B, HW)
 
 
-def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=False, out_planes=False):
+def gemm_gn_rows(M, N, K, HW):
+    """Rows per fused-GroupNorm statistics chunk the library wants for an fp16 GEMM / conv of this shape (64, or 32 / 16 at few rows): the 4th entry
+    of gemm(..., gn=(partial, G, HW, rows)) and the `rows` of the consumer (groupnorm(fused_stats=True), groupnorm_upsample2x, groupnorm_apply_xyz)."""
+    return _L().gp_gemm_gn_rows(M, N, K, HW)
+
+
+def groupnorm(x, w, b, out, G, act, partial, eps=1e-5, ldy=None, fused_stats=False, out_planes=False, rows=64):
     """x (B,HW,C) channels-last -> out rows of stride ldy (default C); in-place allowed.  fused_stats: ``partial``
-    was already filled by the producing gemm(..., gn=(partial, G, HW)) in 64-row chunks."""
+    was already filled by the producing gemm(..., gn=(partial, G, HW[, rows])) in `rows`-row chunks."""
     B, HW, C = x.shape
     code = dtype_code(x.dtype)
     if not fused_stats:
         check(_L().gp_groupnorm_stats(_ptr(_contig(x, "x")), _ptr(partial), B, HW, C, G, code, _stream()), "gp_groupnorm_stats")
     check(_L().gp_groupnorm_apply(_ptr(x), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, HW, C, G, eps, act,
-                                  C if ldy is None else ldy, HW // 64 if fused_stats else 0, _planes_code(x, out_planes, out), _stream()),
+                                  C if ldy is None else ldy, HW // rows if fused_stats else 0, _planes_code(x, out_planes, out), _stream()),
           "gp_groupnorm_apply")
     return out
 
 
-def groupnorm_upsample2x(x, w, b, out, G, act, partial, eps=1e-5):
-    """GroupNorm apply (statistics already in ``partial`` in 64-row chunks, from the producing conv) + act + bilinear x2
+def groupnorm_upsample2x(x, w, b, out, G, act, partial, eps=1e-5, rows=64):
+    """GroupNorm apply (statistics already in ``partial`` in `rows`-row chunks, from the producing conv) + act + bilinear x2
     (align_corners) in one pass: x (B,H,W,C) fp16 -> out (B,2H,2W,C) fp16; bitwise groupnorm(fused_stats=True) + upsample_bilinear2x."""
     B, H, W_, C = x.shape
     check(_L().gp_groupnorm_upsample2x(_ptr(_contig(x, "x")), _ptr(partial), _ptr(w), _ptr(b), _ptr(out), B, H, W_, C, G, eps, act,
-                                       H * W_ // 64, dtype_code(x.dtype), _stream()), "gp_groupnorm_upsample2x")
+                                       H * W_ // rows, dtype_code(x.dtype), _stream()), "gp_groupnorm_upsample2x")
     return out
 
 
-def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5):
-    """GroupNorm apply (statistics already in ``partial`` in 64-row chunks) + act + 1x1 out layer, nothing else written."""
+def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5, rows=64):
+    """GroupNorm apply (statistics already in ``partial`` in `rows`-row chunks) + act + 1x1 out layer, nothing else written."""
     B, HW, C = x.shape
     check(_L().gp_groupnorm_apply_xyz(_ptr(_contig(x, "x")), _ptr(partial), _ptr(w), _ptr(b), _ptr(out_w), _ptr(out_b),
-                                      _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C, G, eps, act, HW // 64, dtype_code(x.dtype),
+                                      _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C, G, eps, act, HW // rows, dtype_code(x.dtype),
                                       _stream()), "gp_groupnorm_apply_xyz")
 
 

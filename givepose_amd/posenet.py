@@ -323,18 +323,25 @@ class PoseNet(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ launch sequence
-    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None, fused=False, out_planes=False):
+    def _gn(self, x, w, b, act, buf, G=32, out=None, ldy=None, fused=False, out_planes=False, rows=64):
         """GroupNorm(32)+act in place (or into a concat target); fused: the producing GEMM already wrote the statistics.
         out_planes (split-operand mode): `out` (another buffer of x's shape) receives the result as the fp16 planes the next
         conv reads."""
         B = x.shape[0]
         C = x.shape[-1]
         xv = x.view(B, -1, C)
-        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy, fused_stats=fused, out_planes=out_planes)
+        ops.groupnorm(xv, w, b, xv if out is None else out, G, act, buf["gn_partial"], ldy=ldy, fused_stats=fused, out_planes=out_planes, rows=rows)
+
+    def _gnrows(self, M, N, K, hw):
+        """Rows per statistics chunk of a fused-GroupNorm launch: the library's choice in plain fp16 mode (16 / 32 where the small-M kernel takes the launch:
+        the detections of one frame), 64 -- the tile kernels' -- otherwise."""
+        if self.split_gemm or self.compute_dtype != torch.float16 or os.environ.get("GP_GN_ROWS64") == "1":
+            return 64
+        return ops.gemm_gn_rows(M, N, K, hw)
 
     @staticmethod
-    def _gnarg(buf, hw):
-        return (buf["gn_partial"], 32, hw)
+    def _gnarg(buf, hw, rows=64):
+        return (buf["gn_partial"], 32, hw, rows)
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):
         """network/xyz_head.py:349-366; feat2d (B*64, Cin) channels-last rows.
@@ -349,29 +356,30 @@ class PoseNet(nn.Module):
         else:
             self._gn(y, W[head + ".gn0_w"], W[head + ".gn0_b"], ACT_GELU, buf)
         cur, r = y, 16
+        rows = {rr: self._gnrows(B * rr * rr, 256, 2304, rr * rr) for rr in (16, 32, 64)}
         fuse_up = FUSE_GN_UPSAMPLE and not pl and y.dtype == torch.float16
         for i in (3, 4, 6, 7, 9, 10):
             if i in (6, 9):
                 r *= 2
                 if fuse_up:   # GroupNorm apply + GELU of conv i-2 and the bilinear x2 in one pass (cur holds the raw conv output)
                     cur = ops.groupnorm_upsample2x(cur, W[f"{head}.c{i - 2}_gw"], W[f"{head}.c{i - 2}_gb"], buf[f"ya{r}"], 32, ACT_GELU,
-                                                   buf["gn_partial"])
+                                                   buf["gn_partial"], rows=rows[r // 2])
                 else:
                     cur = ops.upsample_bilinear2x(cur, buf[f"ya{r}"], out_planes=pl)
             dst = buf[f"yb{r}"] if cur is buf[f"ya{r}"] else buf[f"ya{r}"]
             nxt = {3: 4, 4: 6, 6: 7, 7: 9, 9: 10}.get(i)
-            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r),
+            ops.conv2d_nhwc(cur, W[f"{head}.c{i}_w"], 3, 3, 1, 1, out=dst, gn=self._gnarg(buf, r * r, rows[r]),
                             prefetch=W[f"{head}.c{nxt}_w"] if nxt else None, x_planes=pl)
             if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
                 ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
-                                        W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"])
+                                        W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"], rows=rows[r])
             elif fuse_up and i in (4, 7):
                 pass          # applied by the upsample that follows
             elif pl and i not in (4, 7):   # the next consumer is a conv: planes into the buffer that conv's input just vacated
-                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True, out=cur.view(B, -1, 256), out_planes=True)
+                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True, out=cur.view(B, -1, 256), out_planes=True, rows=rows[r])
                 dst = cur
             else:
-                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True)
+                self._gn(dst, W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], ACT_GELU, buf, fused=True, rows=rows[r])
             cur = dst
 
     def _resnet34(self, W, buf):
@@ -541,9 +549,10 @@ class PoseNet(nn.Module):
         self._gn(p, W["pnp.g0_w"], W["pnp.g0_b"], ACT_RELU, buf)
         for li in (1, 2):
             hw = nxt_hw = (32 >> li) ** 2
-            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"], gn=self._gnarg(buf, hw),
+            rows = self._gnrows(B * hw, 128, 9 * 128, hw)
+            nxt = ops.conv2d_nhwc(p, W[f"pnp.c{li}_w"], 3, 3, 2, 1, out=buf[f"p{li}"], gn=self._gnarg(buf, hw, rows),
                                   prefetch=W["pnp.c2_w"] if li == 1 else W["pnp.fc1_w"])     # (fc1: the first 4 of its 33 MB)
-            self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf, fused=True)
+            self._gn(nxt, W[f"pnp.g{li}_w"], W[f"pnp.g{li}_b"], ACT_RELU, buf, fused=True, rows=rows)
             p = nxt
         ops.gemm(p.view(B, 8192), W["pnp.fc1_w"], buf["fc1"], bias=W["pnp.fc1_b"], epilogue=EPI_LRELU, prefetch=W["pnp.fc2_w"])
         ops.gemm(buf["fc1"], W["pnp.fc2_w"], buf["hh"], bias=W["pnp.fc2_b"], epilogue=EPI_LRELU, M=B, K=1024, ldx=2048, prefetch=W["pnp.fc2z_w"])

@@ -50,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 320 /* round 5: gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
+#define GP_ABI_VERSION 321 /* round 5: gp_gemm_desc.gn_rows + gp_gemm_gn_rows (321); gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -128,7 +128,7 @@ typedef struct gp_gemm_desc {
     int dtype;
     /* optional fused GroupNorm statistics of the OUTPUT (large-tile variants and variant 18, no split-K): per 64 output rows and
      * channel group (sum, sum of squares) -> gn_partial (M/64, gn_groups, 2) fp32, i.e. (B, HW/64, G, 2) when
-     * M = B*gn_hw; consumed by gp_groupnorm_apply(..., chunks = gn_hw/64). NULL = off. */
+     * M = B*gn_hw; consumed by gp_groupnorm_apply(..., chunks = gn_hw/64). NULL = off.  (gn_rows below: other chunk sizes.) */
     float* gn_partial;
     int gn_groups, gn_hw;
     int variant; /* 0 = choose by shape (the product path); otherwise one schedule, for tests and A/B runs: 4 = 128x128 LDS-DMA
@@ -140,7 +140,9 @@ typedef struct gp_gemm_desc {
                   * one fp16 rounding: DESIGN.md 8.2; refused for the other epilogues); 21 = the default of stage-2 fc1 (22 with GP_GELU16=0),
                   * 18 = the small-M latency kernel (few rows -- the detections of one
                   * frame: fp16 in / out, N % 32 == 0, M % 16 == 0 (% 64 with gn_partial), plain GEMM or conv; chosen by variant 0 when its
-                  * estimate beats the tile kernels'; a split-K request is ignored; 218 / 318 / 418 force the 16 / 32 / 64-row tile).
+                  * estimate beats the tile kernels'; a split-K request is ignored; 218 / 318 / 418 force the 16 / 32 / 64-row tile),
+                  * 23 = the row-vector kernel (round 5: a plain fp16 GEMM of M <= 8 rows, K % 512 == 0, N % 8 == 0, bias / GELU / ReLU / LeakyReLU -- ConvPnPNet's fc
+                  * layers over the detections of one frame; chosen by variant 0 for such shapes, GP_GEMM_GEMV=0 keeps it out; a split-K request is ignored).
                   * + 100 n otherwise: timing ablations. */
     /* GP_EPI_LNFOLD_GELU only: ln_stats (M, 2, ln_nslab) fp32 partial (sum, sum of squares) of each X row over
      * ln_nslab channel slabs; ln_colsum (N) fp32; ln_eps.  Requires M % 256 == 0, N % 256 == 0, fp16 output. */
@@ -176,7 +178,15 @@ typedef struct gp_gemm_desc {
     int residual_f32;
     void* c16;
     int ldc16;
+    /* fused GroupNorm statistics (gn_partial != NULL): rows per statistics chunk, 0 = 64.  16 / 32: gn_partial is (M/gn_rows, gn_groups, 2) and the
+     * consumers take chunks = gn_hw/gn_rows; the small-M kernel (variant 18) only -- gp_gemm fails where it cannot take the launch.  Ask
+     * gp_gemm_gn_rows() which value to use for a shape. */
+    int gn_rows;
 } gp_gemm_desc;
+/* Rows per statistics chunk the library wants for a fused-GroupNorm fp16 GEMM / conv of M rows (M = B * hw), N columns, K: 64 (the tile kernels'
+ * chunk) or, where the small-M latency kernel takes the launch and a smaller tile is faster by its cost model, 32 / 16 (round 5: the heads' 3x3 convs
+ * of network/xyz_head.py:241-316 at 1-4 crops).  Pure function of the shape and of GP_GEMM_SMALLM. */
+int gp_gemm_gn_rows(int M, int N, int K, int hw);
 int gp_gemm(const gp_gemm_desc* d, void* stream);
 
 /* fp32 rows -> the two fp16 planes of the split-operand mode: hi (rows, cols) at `planes`, lo' plane_stride elements behind

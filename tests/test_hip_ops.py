@@ -233,33 +233,50 @@ def test_gemm_small_m_latency_variant():
         out = o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18)
         assert rel_err(out, ref) < TOL[dt], cfg
         assert torch.equal(o.conv2d_nhwc(xp, wp, k, k, s_, p_, bias=b.cuda(), epilogue=o.EPI_GELU, variant=18), out)
-    # fused GroupNorm statistics (64-row workgroup tiles; 8 and 4 channels per group; plain GEMM and conv): the statistics the kernel
-    # leaves in 64-row chunks normalise its output exactly as a separate statistics pass over that output does
+    # fused GroupNorm statistics (64-, 32- and 16-row workgroup tiles = statistics chunks, gp_gemm_desc.gn_rows; 8 and 4 channels per group; plain GEMM and
+    # conv): the statistics the kernel leaves in its chunks normalise its output exactly as a separate statistics pass over that output does
     for (Bc, HW, N, K, conv) in [(1, 256, 256, 256, None), (2, 64, 128, 512, None), (1, 1024, 256, 2304, 32), (3, 256, 128, 1152, 16)]:
         G = 32
-        if conv:
-            Cin = K // 9
-            xi = q(rnd(Bc, conv, conv, Cin, seed=174), dt).to("cuda", dt)
-            w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
-            part = torch.zeros(1 << 16, device="cuda")
-            y = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=18, gn=(part, G, HW)).view(Bc, HW, N)
-            y7 = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW)).view(Bc, HW, N)
-        else:
-            xi = q(rnd(Bc * HW, K, seed=174), dt).to("cuda", dt)
-            w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
-            part = torch.zeros(1 << 16, device="cuda")
-            y = torch.empty(Bc, HW, N, dtype=dt, device="cuda")
-            o.gemm(xi, w, y.view(-1, N), variant=18, gn=(part, G, HW))
-            y7 = torch.empty_like(y)
-            o.gemm(xi, w, y7.view(-1, N), variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW))
-        assert rel_err(y, y7.float().cpu()) < 2e-3, (Bc, HW, N, K)
-        gw, gb = (1 + 0.1 * rnd(N, seed=176)).cuda(), (0.1 * rnd(N, seed=177)).cuda()
-        fused = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, part, fused_stats=True)
-        sep = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, torch.zeros(1 << 16, device="cuda"))
-        # (the fused statistics are of the fp32 values before the fp16 store, the separate pass reads the stored fp16: not bitwise)
-        assert rel_err(fused, sep.float().cpu()) < 2e-3, (Bc, HW, N, K)
-        ref = F.gelu(F.group_norm(y.float().cpu().permute(0, 2, 1), G, gw.cpu(), gb.cpu(), 1e-5)).permute(0, 2, 1)
-        assert rel_err(fused, ref) < TOL[dt], (Bc, HW, N, K)
+        y64 = None
+        for rows in (64, 32, 16):
+            gn = lambda part_: (part_, G, HW) if rows == 64 else (part_, G, HW, rows)       # (the 3-tuple form = 64-row chunks)
+            if conv:
+                Cin = K // 9
+                xi = q(rnd(Bc, conv, conv, Cin, seed=174), dt).to("cuda", dt)
+                w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
+                part = torch.zeros(1 << 16, device="cuda")
+                y = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=18, gn=gn(part)).view(Bc, HW, N)
+                y7 = o.conv2d_nhwc(xi, w, 3, 3, 1, 1, variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW)).view(Bc, HW, N)
+            else:
+                xi = q(rnd(Bc * HW, K, seed=174), dt).to("cuda", dt)
+                w = q(rnd(N, K, seed=175, scale=K ** -0.5), dt).to("cuda", dt)
+                part = torch.zeros(1 << 16, device="cuda")
+                y = torch.empty(Bc, HW, N, dtype=dt, device="cuda")
+                o.gemm(xi, w, y.view(-1, N), variant=18, gn=gn(part))
+                y7 = torch.empty_like(y)
+                o.gemm(xi, w, y7.view(-1, N), variant=7, gn=(torch.zeros(1 << 16, device="cuda"), G, HW))
+            assert rel_err(y, y7.float().cpu()) < 2e-3, (Bc, HW, N, K, rows)
+            if y64 is None:
+                y64 = y.clone()
+            else:
+                assert torch.equal(y, y64), (Bc, HW, N, K, rows)        # the tile height changes which workgroup computes a value, not the value
+            gw, gb = (1 + 0.1 * rnd(N, seed=176)).cuda(), (0.1 * rnd(N, seed=177)).cuda()
+            fused = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, part, fused_stats=True, rows=rows)
+            sep = o.groupnorm(y, gw, gb, torch.empty_like(y), G, o.ACT_GELU, torch.zeros(1 << 16, device="cuda"))
+            # (the fused statistics are of the fp32 values before the fp16 store, the separate pass reads the stored fp16: not bitwise)
+            assert rel_err(fused, sep.float().cpu()) < 2e-3, (Bc, HW, N, K, rows)
+            ref = F.gelu(F.group_norm(y.float().cpu().permute(0, 2, 1), G, gw.cpu(), gb.cpu(), 1e-5)).permute(0, 2, 1)
+            assert rel_err(fused, ref) < TOL[dt], (Bc, HW, N, K, rows)
+            if conv and rows < 64:      # the other two consumers of fused statistics read the same chunks
+                up = o.groupnorm_upsample2x(y.view(Bc, conv, conv, N), gw, gb, torch.empty(Bc, 2 * conv, 2 * conv, N, dtype=dt, device="cuda"), G, o.ACT_GELU, part, rows=rows)
+                up_ref = o.upsample_bilinear2x(fused.view(Bc, conv, conv, N), torch.empty_like(up))
+                assert torch.equal(up, up_ref), (Bc, HW, N, K, rows)
+    # chunk rows the library asks for: 64 wherever the small-M kernel would not take the launch; a multiple of 16 that divides M otherwise
+    assert o.gemm_gn_rows(64 * 4096, 256, 2304, 4096) == 64 and o.gemm_gn_rows(256, 256, 2304, 256) in (16, 32) and o.gemm_gn_rows(256, 100, 2304, 256) == 64
+    # 16- / 32-row chunks exist in the small-M kernel only: a launch it cannot take fails instead of writing 64-row chunks the consumer would misread
+    with pytest.raises(RuntimeError, match="gn_rows"):
+        o.gemm(x32h := rnd(256, 128, seed=178).cuda().half(), rnd(64, 128, seed=179).cuda().half(), torch.empty(256, 64, dtype=torch.float32, device="cuda"),
+               gn=(torch.zeros(1 << 12, device="cuda"), 16, 64, 16))
     # refused loudly where it does not apply: fp32 storage, fp32 output, N not a multiple of 32
     x32, w32 = rnd(64, 128, seed=172).cuda(), rnd(64, 128, seed=173).cuda()
     with pytest.raises(RuntimeError, match="variant 18"):
@@ -268,6 +285,39 @@ def test_gemm_small_m_latency_variant():
         o.gemm(x32.half(), w32.half(), torch.empty(64, 64, device="cuda"), variant=18)
     with pytest.raises(RuntimeError, match="variant 18"):
         o.gemm(x32.half(), w32[:48].half().contiguous(), torch.empty(64, 48, dtype=dt, device="cuda"), variant=18)
+
+
+def test_gemm_row_vector_variant():
+    """Variant 23 (round 5): M <= 8 rows -- ConvPnPNet's fc layers over the detections of one frame (network/conv_pnp_net.py:186-199) -- a wave per two output
+    columns, weights straight into registers, v_dot2 into fp32.  Against torch on the fp16-rounded operands; chosen automatically for such shapes; replay-bitwise;
+    refused where it does not apply."""
+    import givepose_amd.ops as o
+    dt = torch.float16
+    for (M, N, K, ldx, epi) in [(1, 2048, 8192, 8192, o.EPI_LRELU), (4, 2048, 8192, 8192, o.EPI_LRELU), (3, 256, 1024, 2048, o.EPI_LRELU), (8, 256, 1024, 2048, o.EPI_NONE),
+                                (5, 64, 512, 512, o.EPI_RELU), (2, 8, 4608, 4608, o.EPI_GELU)]:
+        xfull = q(rnd(M, ldx, seed=181), dt)
+        w = q(rnd(N, K, seed=182, scale=K ** -0.5), dt)
+        b = rnd(N, seed=183)
+        off = ldx - K                                    # (fc2z reads the second half of fc1's rows: conv_pnp_net.py:196)
+        x = xfull[:, off:]
+        v = x @ w.t() + b
+        ref = {o.EPI_NONE: v, o.EPI_LRELU: F.leaky_relu(v, 0.1), o.EPI_RELU: F.relu(v), o.EPI_GELU: F.gelu(v)}[epi]
+        xg, wg, bg = xfull.to("cuda", dt), w.to("cuda", dt), b.cuda()
+        outs = []
+        for variant in (23, 0, 23):
+            out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            o.gemm(xg[:, off:], wg, out, bias=bg, epilogue=epi, variant=variant, M=M, K=K, ldx=ldx)
+            outs.append(out)
+            assert rel_err(out, ref) < TOL[dt], (M, N, K, epi, variant)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K)      # the automatic choice IS variant 23 here; replays agree bitwise
+        out32 = torch.full((M, N), float("nan"), device="cuda")                                 # fp32 output (fc2 / fc2z feed the fp32 pose heads)
+        o.gemm(xg[:, off:], wg, out32, bias=bg, epilogue=epi, variant=23, M=M, K=K, ldx=ldx)
+        assert rel_err(out32, ref) < TOL[dt] and torch.equal(out32.half(), outs[0]), (M, N, K)
+    x9, w9 = rnd(16, 512, seed=184).cuda().half(), rnd(64, 512, seed=185).cuda().half()
+    with pytest.raises(RuntimeError, match="variant 23"):
+        o.gemm(x9, w9, torch.empty(16, 64, dtype=dt, device="cuda"), variant=23)                 # 16 rows
+    with pytest.raises(RuntimeError, match="variant 23"):
+        o.gemm(x9[:4, :256].contiguous(), w9[:, :256].contiguous(), torch.empty(4, 64, dtype=dt, device="cuda"), variant=23)     # K = 256
 
 
 @pytest.mark.parametrize("variant", [16, 17])

@@ -395,7 +395,8 @@ def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
 
 
 @pytest.mark.parametrize("B,pins", [
-    (4, {"gemm v7 M1024 N2048 K512 epi1": 27, "gemm v18 M1024 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v18 32x32": 4, "conv3x3 s1 v18 16x16": 4}),
+    (4, {"gemm v7 M1024 N2048 K512 epi1": 27, "gemm v18 M1024 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v18 32x32": 4, "conv3x3 s1 v18 16x16": 4,
+         "conv3x3 s1 v18 16x16 Cin256 Cout256 M1024 +gn32": 4, "gemm v23 M4 N2048 K8192 epi3": 1, "gemm v23 M4 N256 K1024 epi3": 2}),
     (8, {"gemm v7 M2048 N2048 K512 epi1": 27, "gemm v18 M2048 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4}),
     (16, {"gemm v7 M4096 N2048 K512 epi1": 27, "gemm v7 M4096 N512 K2048 epi4": 27, "conv3x3 s1 v13 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4})])
 def test_small_batch_wiring_is_pinned(net16, B, pins):
