@@ -2370,7 +2370,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
                          (!d->bias || ((size_t)d->bias & 15) == 0);
     // few rows (the detections of one frame): the latency kernel (variant 18), whatever split-K factor the caller worked out for the
     // tile kernels.  GP_GEMM_SMALLM=0 keeps it out of the automatic choice (A/B switch)
-    const bool smallm_ok = d->dtype == GP_F16 && !split && !d->out_f32 && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
+    const bool smallm_ok = d->dtype == GP_F16 && !split && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
+                           (!d->out_f32 || (d->epilogue <= GP_EPI_LRELU && !d->gn_partial && ((size_t)d->C & 15) == 0)) &&      // fp32 out: the activation epilogues (round 5)
                            (!d->gn_partial || (d->M % (d->gn_rows ? d->gn_rows : 64) == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
                            d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
                            ((size_t)d->W & 15) == 0 && ((size_t)d->C & 7) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&

@@ -23,6 +23,8 @@ from . import _lib, ops, synth
 from ._lib import (ACT_GELU, ACT_RELU, EPI_GELU, EPI_LNFOLD_GELU, EPI_LRELU, EPI_NONE, EPI_SCALE_RES)
 from .config import PoseNetConfig
 
+OM_LD = 128     # row length of the DCNv3 offset | mask projection output (108 used columns)
+
 
 class _Node(nn.Module):
     """Container mirroring one level of the reference module tree (names only)."""
@@ -228,8 +230,12 @@ class PoseNet(nn.Module):
                 W[q + "dw_w"] = lowp(sd[d + "dw_conv.0.weight"].reshape(256, 9).t())
                 W[q + "dw_b"] = f32(sd[d + "dw_conv.0.bias"])
                 W[q + "ln_w"], W[q + "ln_b"] = f32(sd[d + "dw_conv.1.1.weight"]), f32(sd[d + "dw_conv.1.1.bias"])
-                W[q + "om_w"] = gw(torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0))
-                W[q + "om_b"] = f32(torch.cat([sd[d + "offset.bias"], sd[d + "mask.bias"]], 0))
+                # offset (72) | mask (36) projections as one GEMM, padded with zero rows to 128 columns: N % 32 == 0 lets the few-crop case run on the
+                # small-M kernel (a 108-wide output took a 128 x 128 tile: 12-14 us per launch at one crop); the consumers read columns 0..107 of rows of 128
+                omw = torch.cat([sd[d + "offset.weight"], sd[d + "mask.weight"]], 0)
+                omb = torch.cat([sd[d + "offset.bias"], sd[d + "mask.bias"]], 0)
+                W[q + "om_w"] = gw(torch.cat([omw, omw.new_zeros(OM_LD - omw.shape[0], omw.shape[1])], 0))
+                W[q + "om_b"] = f32(torch.cat([omb, omb.new_zeros(OM_LD - omb.shape[0])], 0))
                 W[q + "in_w"], W[q + "in_b"] = gw(sd[d + "input_proj.weight"]), f32(sd[d + "input_proj.bias"])
                 # input_proj(conv1x1(x)) is one linear map: fold the two (fp32 product, then storage rounding) so the
                 # full-resolution 256-channel `conv` output is only materialised for the prefix the dw_conv branch reads
@@ -307,7 +313,7 @@ class PoseNet(nn.Module):
         for li, r in enumerate((64, 32, 16)):
             buf[f"e_in{li}"], buf[f"e_proj{li}"] = e(B, r, r, 256), e(B, r, r, 256)
             buf[f"e_x1{li}"] = e(B * r * r // 4, 256)
-            buf[f"e_om{li}"] = f(B * r * r // 4, 108)
+            buf[f"e_om{li}"] = f(B * r * r // 4, OM_LD)
             buf[f"e_g{li}"], buf[f"e_o{li}"] = e(B, r // 2, r // 2, 256), e(B, r // 2, r // 2, 256)
         if cfg.nocsmap_encoder == "att":
             buf["a_patch"], buf["a_x"], buf["a_h"] = e(B * 64, 192), e(B * 64, 256), e(B * 64, 256)
@@ -510,7 +516,9 @@ class PoseNet(nn.Module):
                 for g0 in range(0, B, Bg):
                     gs = slice(g0, g0 + Bg)
                     nq = Bg * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
-                    npre = min(Bg * r * r, nq + r + 8)   # + one image row of halo for the 3x3 depth-wise conv
+                    # + one image row of halo for the 3x3 depth-wise conv; rounded up to 16 rows so that the few-crop case (88 / 296 rows at one crop) takes the
+                    # small-M GEMM kernel (M % 16 == 0) instead of a 128 x 128 tile (the extra rows are rows of the same map, computed and not read)
+                    npre = min(Bg * r * r, (nq + r + 8 + 15) // 16 * 16)
                     xin_g = xin[gs]
                     if li == 0:
                         ops.pointwise_k3(buf["nocs_nhwc4"][g0 * r * r:][:npre], W[q + "conv_w"], W[q + "conv_b"], xin_g.view(-1, 256)[:npre])
@@ -521,7 +529,7 @@ class PoseNet(nn.Module):
                     ops.dwconv_ln(xin_g, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], x1_g, 3, act=ACT_GELU, n_pixels=nq)
                     ops.gemm(x1_g, W[q + "om_w"], om_g, bias=W[q + "om_b"])
                     ops.dcnv3_forward_into(buf[f"e_proj{li}"][gs], om_g, om_g[:, 72:], buf[f"e_g{li}"][gs], 3, 2, 1, 1, 4, 64, 1.0,
-                                           off_ld=108, mask_ld=108, mask_is_logits=True)
+                                           off_ld=OM_LD, mask_ld=OM_LD, mask_is_logits=True)
                 y = buf[f"e_o{li}"]
                 ops.gemm(buf[f"e_g{li}"].view(-1, 256), W[q + "out_w"], y.view(-1, 256), bias=W[q + "out_b"],
                          gn=self._gnarg(buf, ro * ro))

@@ -281,8 +281,9 @@ def test_gemm_small_m_latency_variant():
     x32, w32 = rnd(64, 128, seed=172).cuda(), rnd(64, 128, seed=173).cuda()
     with pytest.raises(RuntimeError, match="variant 18"):
         o.gemm(x32, w32, torch.empty(64, 64, device="cuda"), variant=18)
-    with pytest.raises(RuntimeError, match="variant 18"):
-        o.gemm(x32.half(), w32.half(), torch.empty(64, 64, device="cuda"), variant=18)
+    # fp16 operands with an fp32 output (the DCNv3 offset | mask projection, ops_dcnv3/modules/dcnv3.py:341-349): taken since round 5, activation epilogues only
+    o32 = o.gemm(x32.half(), w32.half(), torch.empty(64, 64, device="cuda"), variant=18)
+    assert rel_err(o32, x32.half().float().cpu() @ w32.half().float().cpu().t()) < TOL[dt]
     with pytest.raises(RuntimeError, match="variant 18"):
         o.gemm(x32.half(), w32[:48].half().contiguous(), torch.empty(64, 48, dtype=dt, device="cuda"), variant=18)
 
