@@ -58,27 +58,29 @@ __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 acc
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
 }
 
-template <int C, int G16>     // G16: GELU on packed fp16 (common.hpp gelu16_slice), the default; 0: the fp32 polynomial (GP_GELU16=0)
-__global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
+// NWV = waves per workgroup (32 rows each): 8 -- one workgroup per CU -- or (C = 128, round 5, GP_MLP_WAVES=4) 4: 66 KB of LDS, so two INDEPENDENT workgroups share a CU
+// instead of eight waves in lock step behind one barrier (one workgroup's GELU / epilogue beside the other's MFMAs)
+template <int C, int G16, int NWV = 8>     // G16: GELU on packed fp16 (common.hpp gelu16_slice), the default; 0: the fp32 polynomial (GP_GELU16=0)
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void convnext_mlp_kernel(const MlpKP p) {
     constexpr int HD = 4 * C, NCH = HD / 32, KS = C / 32, CT = C / 16, MT = 2;
     constexpr int ROWB = C * 2;                        // bytes per W1 row
     constexpr int W1B = 32 * ROWB, W2B = C * 64;       // bytes per chunk
-    constexpr int STAGE = W1B + W2B, NS = 4, LEAD = 3;
-    constexpr int I1 = W1B / 1024 / 8, I2 = W2B / 1024 / 8, G = I1 + I2;   // LDS-DMA instructions per wave and chunk
+    constexpr int STAGE = W1B + W2B, NS = (NWV == 4 && C == 256) ? 2 : 4, LEAD = NS - 1;     // (C = 256 with 4 waves: a 2-stage ring = 68 KB, two workgroups per CU: measured, no gain, not instantiated)
+    constexpr int I1 = W1B / 1024 / NWV, I2 = W2B / 1024 / NWV, G = I1 + I2;   // LDS-DMA instructions per wave and chunk
     constexpr int CPR1 = ROWB / 16, RPI1 = 64 / CPR1;  // 16-byte chunks per W1 row, W1 rows per DMA instruction
     constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
-    constexpr int RING = NS * STAGE, SMEM = (RING + HD * 4) > 8 * SLAB ? (RING + HD * 4) : 8 * SLAB;
+    constexpr int RING = NS * STAGE, SMEM = (RING + HD * 4) > NWV * SLAB ? (RING + HD * 4) : NWV * SLAB;
     static_assert(SMEM <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * 256 + wave * 32;   // an XCD's workgroups = a contiguous run of rows (common.hpp)
+    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * (NWV * 32) + wave * 32;   // an XCD's workgroups = a contiguous run of rows (common.hpp)
 
     // ---- bias of the hidden layer -> LDS (read back per chunk as the accumulators' initial value)
     float* b1s = reinterpret_cast<float*>(smem + RING);
-    for (int i = tid; i < HD / 4; i += 512) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+    for (int i = tid; i < HD / 4; i += NWV * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
 
     // ---- this wave's x rows as B fragments: lane (fr, fq) holds x[m][ks*32 + fq*8 .. +8]
     uint4 xf[MT][KS];
@@ -90,25 +92,34 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
 
     // ---- DMA sources.  W1 chunk image: [32 rows][ROWB], 16-byte chunk ^= row & 15; W2 chunk image: [C rows][64 B],
     //      chunk ^= (-(row>>2)) & 3 inside each group of 16 rows (both involutions are repeated on the fragment reads)
-    const char* w1src[I1];
-    const char* w2src[I2];
+    //      (32-bit per-lane byte offsets against a wave-uniform base: one register per DMA instruction instead of a 64-bit pointer)
+    constexpr bool SB = true;          // (64-bit per-lane pointers: 4-8 registers more -- C = 256 with 4 waves spilled -- and 2-5 us slower at C = 128)
+    unsigned w1off[I1], w2off[I2];
 #pragma unroll
     for (int i = 0; i < I1; ++i) {
-        const int r = (i * 8 + wave) * RPI1 + lane / CPR1, pc = lane % CPR1;
-        w1src[i] = reinterpret_cast<const char*>(p.W1 + (long)r * C + ((pc ^ (r & 15)) << 3));
+        const int r = (i * NWV + wave) * RPI1 + lane / CPR1, pc = lane % CPR1;
+        w1off[i] = (unsigned)((r * C + ((pc ^ (r & 15)) << 3)) * 2);
     }
 #pragma unroll
     for (int i = 0; i < I2; ++i) {
-        const int lr = lane >> 2, r = (i * 8 + wave) * 16 + lr;
-        w2src[i] = reinterpret_cast<const char*>(p.W2p + (long)r * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3));
+        const int lr = lane >> 2, r = (i * NWV + wave) * 16 + lr;
+        w2off[i] = (unsigned)((r * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3)) * 2);
     }
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
     auto stage = [&](int buf, int ch) {
         const unsigned s1 = lds0 + buf * STAGE + wave * 1024, s2 = s1 + W1B;
+        const char* b1p = reinterpret_cast<const char*>(p.W1) + (long)ch * W1B;
+        const char* b2p = reinterpret_cast<const char*>(p.W2p) + (long)ch * 64;
 #pragma unroll
-        for (int i = 0; i < I1; ++i) glds16(w1src[i] + (long)ch * W1B, s1 + i * 8192);
+        for (int i = 0; i < I1; ++i) {
+            if constexpr (SB) glds16_sb(b1p, w1off[i], s1 + i * NWV * 1024);
+            else glds16(b1p + w1off[i], s1 + i * NWV * 1024);
+        }
 #pragma unroll
-        for (int i = 0; i < I2; ++i) glds16(w2src[i] + (long)ch * 64, s2 + i * 8192);
+        for (int i = 0; i < I2; ++i) {
+            if constexpr (SB) glds16_sb(b2p, w2off[i], s2 + i * NWV * 1024);
+            else glds16(b2p + w2off[i], s2 + i * NWV * 1024);
+        }
     };
 
     f32x4 acc2[CT][MT];
@@ -128,8 +139,8 @@ __global__ __launch_bounds__(512) void convnext_mlp_kernel(const MlpKP p) {
     for (int ch = 0; ch < NCH; ++ch) {
         // own DMA of chunk ch landed (chunks ch+1, ch+2 stay in flight), then the barrier publishes it and retires
         // every wave's reads of chunk ch-1, whose slot the DMA of chunk ch+3 is about to overwrite
-        if (ch + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-        else if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        if (LEAD >= 3 && ch + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (LEAD >= 2 && ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -565,6 +576,13 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
         GP_LAUNCH_CHECK("gp_convnext_mlp");
     }
     const dim3 grid((unsigned)(M / 256));
+    // C = 128 (round 5): 4-wave workgroups, two per CU (66 KB of LDS each): 205 -> 177-183 us per 128 crops against eight waves behind one barrier
+    // (profiles/r05_mlp_waves_ab.txt; C = 256's ring leaves no room for a second workgroup -- with a 2-stage ring it has, and gains nothing).  GP_MLP_WAVES=8: A/B switch
+    static const int mlp_waves = [] { const char* e = getenv("GP_MLP_WAVES"); return e ? atoi(e) : 4; }();
+    if (gp_gelu16_enabled() && C == 128 && mlp_waves == 4) {
+        hipLaunchKernelGGL((convnext_mlp_kernel<128, 1, 4>), dim3((unsigned)(M / 128)), dim3(256), 0, s, p);
+        GP_LAUNCH_CHECK("gp_convnext_mlp");
+    }
     if (gp_gelu16_enabled()) {
         if (C == 128) hipLaunchKernelGGL((convnext_mlp_kernel<128, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((convnext_mlp_kernel<256, 1>), grid, dim3(512), 0, s, p);
