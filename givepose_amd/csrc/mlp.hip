@@ -58,14 +58,19 @@ __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 acc
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&a), *reinterpret_cast<const half8*>(&b), acc, 0, 0, 0);
 }
 
-// NWV = waves per workgroup (32 rows each): 8 -- one workgroup per CU -- or (C = 128, round 5, GP_MLP_WAVES=4) 4: 66 KB of LDS, so two INDEPENDENT workgroups share a CU
-// instead of eight waves in lock step behind one barrier (one workgroup's GELU / epilogue beside the other's MFMAs)
+// NWV = waves per workgroup (32 rows each): 8 -- one workgroup per CU -- or (C = 128, round 5; GP_MLP_WAVES=8 switches back) 4: 50 KB of LDS, so three INDEPENDENT workgroups
+// share a CU instead of eight waves in lock step behind one barrier (one workgroup's GELU / epilogue beside the others' MFMAs): 205 -> 163 us per 128 crops
+// The 4-wave form is trimmed to 168 registers (four GELU chains and four W2 fragments at a time) and a 3-stage ring (50 KB of LDS): THREE workgroups per CU
+// (-DGP_MLP_WGS=2: the two-workgroup form with the 8-wave kernel's register choices and 4-stage ring, for A/B builds)
+#ifndef GP_MLP_WGS
+#define GP_MLP_WGS 3
+#endif
 template <int C, int G16, int NWV = 8>     // G16: GELU on packed fp16 (common.hpp gelu16_slice), the default; 0: the fp32 polynomial (GP_GELU16=0)
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void convnext_mlp_kernel(const MlpKP p) {
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? GP_MLP_WGS : 1) void convnext_mlp_kernel(const MlpKP p) {
     constexpr int HD = 4 * C, NCH = HD / 32, KS = C / 32, CT = C / 16, MT = 2;
     constexpr int ROWB = C * 2;                        // bytes per W1 row
     constexpr int W1B = 32 * ROWB, W2B = C * 64;       // bytes per chunk
-    constexpr int STAGE = W1B + W2B, NS = (NWV == 4 && C == 256) ? 2 : 4, LEAD = NS - 1;     // (C = 256 with 4 waves: a 2-stage ring = 68 KB, two workgroups per CU: measured, no gain, not instantiated)
+    constexpr int STAGE = W1B + W2B, NS = (NWV == 4 && C == 256) ? 2 : (NWV == 4 && GP_MLP_WGS == 3) ? 3 : 4, LEAD = NS - 1;     // (C = 256 with 4 waves: a 2-stage ring = 68 KB, two workgroups per CU: measured, no gain, not instantiated)
     constexpr int I1 = W1B / 1024 / NWV, I2 = W2B / 1024 / NWV, G = I1 + I2;   // LDS-DMA instructions per wave and chunk
     constexpr int CPR1 = ROWB / 16, RPI1 = 64 / CPR1;  // 16-byte chunks per W1 row, W1 rows per DMA instruction
     constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void convnext_mlp_kerne
                     for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = mma16(a1[ks][nt], xf[mt][k0 + ks], acc1[nt][mt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        constexpr int GC = CT > 8 ? 2 : CT;          // W2 fragments resident at a time
+        constexpr int GC = CT > 8 ? 2 : (NWV == 4 && GP_MLP_WGS == 3) ? 4 : CT;          // W2 fragments resident at a time
         uint4 a2[GC];
 #pragma unroll
         for (int ct = 0; ct < GC; ++ct) a2[ct] = *reinterpret_cast<const uint4*>(s2 + ct * 1024);
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void convnext_mlp_kerne
             if (p.dbg == 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) hw[i] = __builtin_bit_cast(unsigned, half2v{(half_t)v[i][0], (half_t)v[i][1]});
-            } else if constexpr (C == 128) {
+            } else if constexpr (C == 128 && !(NWV == 4 && GP_MLP_WGS == 3)) {
                 gelu16_xn<8>(v, hw);
             } else {   // C = 256: four chains at a time (register budget)
                 gelu16_xn<4>(v, hw);
@@ -576,7 +581,7 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
         GP_LAUNCH_CHECK("gp_convnext_mlp");
     }
     const dim3 grid((unsigned)(M / 256));
-    // C = 128 (round 5): 4-wave workgroups, two per CU (66 KB of LDS each): 205 -> 177-183 us per 128 crops against eight waves behind one barrier
+    // C = 128 (round 5): 4-wave workgroups, three per CU (50 KB of LDS each): 205 -> 163 us per 128 crops against eight waves behind one barrier
     // (profiles/r05_mlp_waves_ab.txt; C = 256's ring leaves no room for a second workgroup -- with a 2-stage ring it has, and gains nothing).  GP_MLP_WAVES=8: A/B switch
     static const int mlp_waves = [] { const char* e = getenv("GP_MLP_WAVES"); return e ? atoi(e) : 4; }();
     if (gp_gelu16_enabled() && C == 128 && mlp_waves == 4) {
