@@ -2251,6 +2251,11 @@ static bool gemv_enabled() {   // GP_GEMM_GEMV=0: A/B switch, keeps the row-vect
     return on;
 }
 
+static int smallm_max_rows() {   // rows up to which variant 0 may pick the latency kernel; GP_GEMM_SMALLM_MAXROWS=<n>: A/B switch
+    static const int n = [] { const char* e = getenv("GP_GEMM_SMALLM_MAXROWS"); return e && atoi(e) > 0 ? atoi(e) : 16384; }();
+    return n;
+}
+
 static bool smallm_enabled() {   // GP_GEMM_SMALLM=0: A/B switch, keeps the latency kernel (variant 18) out of the automatic choice
     static const bool on = [] { const char* e = getenv("GP_GEMM_SMALLM"); return !(e && e[0] == '0'); }();
     return on;
@@ -2265,7 +2270,7 @@ static long pp_min_tiles() {
 // tile kernels' chunk -- unless the latency kernel would take the launch and a smaller tile is faster by its cost model (few rows: the detections of one
 // frame; 16-row tiles give the heads' 3 x 3 convs at one crop 128 workgroups and two load rounds instead of 32 and three).
 extern "C" int gp_gemm_gn_rows(int M, int N, int K, int hw) {
-    if (M <= 0 || N <= 0 || K <= 0 || N % 32 || M % 16 || hw % 64 || !smallm_enabled() || M > 32768) return 64;
+    if (M <= 0 || N <= 0 || K <= 0 || N % 32 || M % 16 || hw % 64 || !smallm_enabled() || M > smallm_max_rows()) return 64;
     double best = 1e30;
     int mt_best = 4;
     for (int mt = 1; mt <= 4; mt *= 2) {
@@ -2401,9 +2406,11 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         GP_LAUNCH_CHECK("gp_gemm");
     }
     int sm_mt = 0;
+    // (smallm_max_rows(): 16 384 since the end of round 5 -- at 32 768 rows the estimate was 21 us for a launch that takes 32 where a tile kernel takes 16;
+    // at 16 384 rows the latency kernel still wins, 11.6 against 15.6 us: profiles/r05_smallm_cap_ab.txt.  Before:)
     // (the estimate below was fitted on 1-8 crops: the automatic choice stops at 32 768 rows -- 16 crops' worth of the widest map it was
     // measured on -- whatever the estimate says beyond; tests/test_hip_posenet.py pins which launches take it at 4 / 8 / 16 crops)
-    if (smallm_ok && smallm_enabled() && d->M <= 32768) {
+    if (smallm_ok && smallm_enabled() && d->M <= smallm_max_rows()) {
         double best = 1e30;
         const int gn_mt = d->gn_partial ? (d->gn_rows ? d->gn_rows / 16 : 4) : 0;      // fused statistics: the caller's chunk rows ARE the tile rows
         for (int mt = gn_mt ? gn_mt : 1; mt <= (gn_mt ? gn_mt : 4); mt *= 2) {
