@@ -1,9 +1,10 @@
-"""Kernel labels of one eager fp16 forward at the given batch sizes (which schedule runs where): python scripts/dump_labels.py 4 8 16"""
-import sys, ctypes, torch
+"""Kernel labels of one eager fp16 forward at the given batch sizes (which schedule runs where): python scripts/dump_labels.py 4 8 16
+(BB=resnet34: the ResNet-34 trunk variant)"""
+import os, sys, ctypes, torch
 sys.path.insert(0, ".")
 from givepose_amd import PoseNet, PoseNetConfig, synth, _lib
 lib = _lib.load()
-net = PoseNet(PoseNetConfig(), dtype=torch.float16, seed=0).cuda()
+net = PoseNet(PoseNetConfig(main_backbone=os.environ.get("BB", "convnext")), dtype=torch.float16, seed=0).cuda()
 for B in [int(a) for a in sys.argv[1:]]:
     data = {k: torch.from_numpy(v) for k, v in synth.synth_batch(B, seed=3).items()}
     net.forward_device(data)
