@@ -48,6 +48,7 @@ class PoseNetConfig:
     # build-side switch (fp16 storage only, round 5): stage 2 (C = 512) runs fc1 -> GELU -> fc2 as ONE launch (convnext_mlp512_kernel) from 128 crops per launch up:
     # the 134 MB hidden tensor never exists (7.2 GB of HBM traffic per 128 crops), but the kernel alone is 8 % slower than the two launches (one wave per SIMD);
     # end to end: DESIGN.md 8.5.  Off by default.
+    gnxyz16: bool = True                  # fp16 mode: GroupNorm apply + GELU + 1x1 out layer of the xyz heads on packed fp16 arithmetic (GP_ACT_PACKED16)
     fuse_mlp512: bool = False
 
     @property

@@ -1013,6 +1013,11 @@ __global__ __launch_bounds__(256) void gn_apply_xyz_kernel(const T* __restrict__
 // 16-byte load each), splits them into fp16 hi + lo, and 8 x 3 MFMAs against the (3 -> 16 rows, fp16 hi + lo) out-layer weights
 // do the 3 x 256 dot products and their reduction in fp32 accuracy: no per-pixel cross-lane sums, no fp32 dot FMAs.
 // scale / shift per channel in LDS.
+// H16 (round 5; act | GP_ACT_PACKED16: PoseNet's fp16 mode asks for it, PoseNetConfig.gnxyz16 / GP_GNXYZ16=0 switch back): the affine and the GELU on PACKED fp16 -- v_pk_fma_f16 on the stored fp16 values against (scale, shift)
+// pairs rounded to fp16, then gelu16_slice (common.hpp) -- and the packed results go into the MFMA as they stand (hi / lo weight fragments as before, no lo activations):
+// 13 VALU operations per value PAIR instead of ~34 (2 conversions + 2 FMAs + 2 x 12 polynomial + 6 for the hi / lo split): the fp32 form is VALU-bound (81 us per
+// 128 crops at 3.5 TB/s where the same pass without an out layer streams at 5.7), profiles/r05_gnxyz16_ab.txt.
+template <bool H16>
 __global__ __launch_bounds__(256, 4) void gn_apply_xyz_mfma_kernel(const half_t* __restrict__ x, const float* __restrict__ partial,
                                                                 const float* __restrict__ w, const float* __restrict__ bb,
                                                                 const float* __restrict__ ow, const float* __restrict__ ob,
@@ -1043,11 +1048,14 @@ __global__ __launch_bounds__(256, 4) void gn_apply_xyz_mfma_kernel(const half_t*
         a_s[ks][1][lane] = lo8;
     }
     gn_finalize(partial, b, chunks, G, inv_count, eps, st);
+    __shared__ __attribute__((aligned(16))) half_t sc16_s[C], sh16_s[C];
     {
         const int cpg = C / G, g = tid / cpg;
         const float s = st[g][1] * w[tid];
         sc_s[tid] = s;
         sh_s[tid] = bb[tid] - st[g][0] * s;
+        sc16_s[tid] = (half_t)s;
+        sh16_s[tid] = (half_t)(bb[tid] - st[g][0] * s);
     }
     __syncthreads();
     const float b0 = ob[0], b1 = ob[1], b2 = ob[2];
@@ -1062,6 +1070,22 @@ __global__ __launch_bounds__(256, 4) void gn_apply_xyz_mfma_kernel(const half_t*
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int c0 = ks * 32 + fq * 8;
+            if constexpr (H16) {
+                const half8 s8 = *reinterpret_cast<const half8*>(sc16_s + c0), h8 = *reinterpret_cast<const half8*>(sh16_s + c0);
+                half2v hx[4], hu[4], hp[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hx[i] = __builtin_elementwise_fma(half2v{xv[ks][2 * i], xv[ks][2 * i + 1]}, half2v{s8[2 * i], s8[2 * i + 1]}, half2v{h8[2 * i], h8[2 * i + 1]});
+                static_for<1, GELU16_SLICES>([&](auto sc) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gelu16_slice<decltype(sc)::value>(f32x2{0.f, 0.f}, hx[i], hu[i], hp[i]);
+                });
+                const half8 a16 = half8{hp[0][0], hp[0][1], hp[1][0], hp[1][1], hp[2][0], hp[2][1], hp[3][0], hp[3][1]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_s[ks][1][lane], a16, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_s[ks][0][lane], a16, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_s + c0), s1 = *reinterpret_cast<const f32x4*>(sc_s + c0 + 4);
             const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh_s + c0), h1 = *reinterpret_cast<const f32x4*>(sh_s + c0 + 4);
             f32x2 v[4];
@@ -1424,7 +1448,9 @@ extern "C" int gp_groupnorm_upsample2x(const void* x, const float* partial, cons
 
 extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const float* w, const float* b,
                                       const float* out_w, const float* out_b, float* out_nchw, float* out_nhwc4, int B,
-                                      int HW, int C, int G, float eps, int act, int chunks_in, int dtype, void* stream) {
+                                      int HW, int C, int G, float eps, int act_in, int chunks_in, int dtype, void* stream) {
+    const bool h16 = (act_in & GP_ACT_PACKED16) != 0;
+    const int act = act_in & 0xff;
     GP_REQUIRE(x && partial && w && b && out_w && out_b && out_nchw && out_nhwc4 && B > 0 && HW > 0, "gp_groupnorm_apply_xyz: bad argument");
     GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_groupnorm_apply_xyz: bad dtype");
     const int esz = dtype == GP_F16 ? 2 : 4;
@@ -1436,8 +1462,10 @@ extern "C" int gp_groupnorm_apply_xyz(const void* x, const float* partial, const
     const float inv_count = 1.0f / ((float)HW * (C / G));
     dim3 grid(cdiv(HW, pxb), B);
     static const bool mfma = [] { const char* e = getenv("GP_GNXYZ_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (dtype == GP_F16 && C == 256 && act == GP_ACT_GELU && 256 % G == 0 && mfma)
-        hipLaunchKernelGGL(gn_apply_xyz_mfma_kernel, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, G, chunks, inv_count, eps, pxb);
+    if (dtype == GP_F16 && C == 256 && act == GP_ACT_GELU && 256 % G == 0 && mfma && h16 && gp_gelu16_enabled())
+        hipLaunchKernelGGL(gn_apply_xyz_mfma_kernel<true>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, G, chunks, inv_count, eps, pxb);
+    else if (dtype == GP_F16 && C == 256 && act == GP_ACT_GELU && 256 % G == 0 && mfma)
+        hipLaunchKernelGGL(gn_apply_xyz_mfma_kernel<false>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, G, chunks, inv_count, eps, pxb);
     else if (dtype == GP_F16)
         hipLaunchKernelGGL(gn_apply_xyz_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, partial, w, b, out_w, out_b, out_nchw, out_nhwc4, HW, C, G, act, chunks, inv_count, eps, pxb);
     else

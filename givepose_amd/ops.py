@@ -467,11 +467,12 @@ def groupnorm_upsample2x(x, w, b, out, G, act, partial, eps=1e-5, rows=64):
     return out
 
 
-def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5, rows=64):
-    """GroupNorm apply (statistics already in ``partial`` in `rows`-row chunks) + act + 1x1 out layer, nothing else written."""
+def groupnorm_apply_xyz(x, w, b, out_w, out_b, out_nchw, out_nhwc4, G, act, partial, eps=1e-5, rows=64, packed16=False):
+    """packed16 (fp16, C = 256, GELU): affine + GELU on packed fp16 arithmetic (GP_ACT_PACKED16), the fp16 mode's form.
+    GroupNorm apply (statistics already in ``partial`` in `rows`-row chunks) + act + 1x1 out layer, nothing else written."""
     B, HW, C = x.shape
     check(_L().gp_groupnorm_apply_xyz(_ptr(_contig(x, "x")), _ptr(partial), _ptr(w), _ptr(b), _ptr(out_w), _ptr(out_b),
-                                      _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C, G, eps, act, HW // rows, dtype_code(x.dtype),
+                                      _ptr(out_nchw), _ptr(out_nhwc4), B, HW, C, G, eps, act | (0x100 if packed16 else 0), HW // rows, dtype_code(x.dtype),
                                       _stream()), "gp_groupnorm_apply_xyz")
 
 

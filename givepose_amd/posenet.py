@@ -378,7 +378,8 @@ class PoseNet(nn.Module):
                             prefetch=W[f"{head}.c{nxt}_w"] if nxt else None, x_planes=pl)
             if i == 10:   # last ConvModule: GN + GELU + the 1x1 out layer in one pass, the 64x64x256 tensor is never written
                 ops.groupnorm_apply_xyz(dst.view(B, r * r, 256), W[f"{head}.c{i}_gw"], W[f"{head}.c{i}_gb"], W[head + ".out_w"],
-                                        W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"], rows=rows[r])
+                                        W[head + ".out_b"], out_nchw, out_nhwc4, 32, ACT_GELU, buf["gn_partial"], rows=rows[r],
+                                        packed16=self.cfg.gnxyz16 and dst.dtype == torch.float16 and os.environ.get("GP_GNXYZ16") != "0")
             elif fuse_up and i in (4, 7):
                 pass          # applied by the upsample that follows
             elif pl and i not in (4, 7):   # the next consumer is a conv: planes into the buffer that conv's input just vacated
