@@ -897,7 +897,10 @@ extern "C" int gp_convnext_stem(const float* img, const float* w, const float* b
     gp_timing_before(s, GP_KC_SMALL, 2.0 * px * 48 * C0, (double)B * 3 * H * W * 4 + (double)px * C0 * (dtype == GP_F16 ? 2 : 4));
     dim3 grid(B * (H / 4) * (W / 4 / PXB));
     static const bool mfma_stem = [] { const char* e = getenv("GP_STEM_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (dtype == GP_F16 && PXB == 64 && mfma_stem && (H / 4) % 4 == 0)
+    // few crops (the detections of one frame): one output row per workgroup -- 64 workgroups per crop instead of 16 (GP_STEM_RPW=4 / 1 forces a form: A/B switch)
+    static const int rpw_env = [] { const char* e = getenv("GP_STEM_RPW"); return e ? atoi(e) : 0; }();
+    const bool rows4 = rpw_env ? rpw_env == 4 : (long)B * (H / 16) * (W / 4 / 64) >= 256;
+    if (dtype == GP_F16 && PXB == 64 && mfma_stem && (H / 4) % 4 == 0 && rows4)
         hipLaunchKernelGGL(stem_mfma_kernel<4>, dim3(B * (H / 16) * (W / 4 / 64)), dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
     else if (dtype == GP_F16 && PXB == 64 && mfma_stem)
         hipLaunchKernelGGL(stem_mfma_kernel<1>, grid, dim3(256), 0, s, img, w, b, ln_w, ln_b, (half_t*)out, H, W, eps);
