@@ -11,8 +11,14 @@ extern "C" int gp_dw_stamps_read(unsigned long long* host) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(gp_dw_stamp_buf), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : 1;
 }
 #define GP_DW_MARK(k) do { if (blockIdx.x == gridDim.x / 2 + 1 && blockIdx.y == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) gp_dw_stamp_buf[(threadIdx.x >> 6) * 16 + (k)] = t__; } } while (0)
+__device__ unsigned long long gp_dwt_stamp_buf[8 * 64];       // dwconv7_ln_tall_kernel (scripts/dw_tall_stamps.py)
+extern "C" int gp_dwt_stamps_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(gp_dwt_stamp_buf), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : 1;
+}
+#define GP_DWT_MARK(k) do { if (blockIdx.x == gridDim.x / 2 + 1) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) gp_dwt_stamp_buf[(threadIdx.x >> 6) * 64 + (k)] = t__; } } while (0)
 #else
 #define GP_DW_MARK(k) do { } while (0)
+#define GP_DWT_MARK(k) do { } while (0)
 #endif
 namespace {
 
@@ -707,6 +713,348 @@ void launch_dw7_raw(const void* x, const void* wt, const float* bias, void* y, f
                        (const half_t*)wt, bias, bias, bias, (half_t*)y, H, W, C, 0.f, 0, stats);
 }
 
+// ---------------------------------------------------------------------------- dw7x7 + LN, 16-pixel-wide maps: 16 x 8 tiles (round 6)
+// ConvNeXt stage 2 (16 x 16 x 512: 27 of the 36 blocks) is one round of workgroups whatever the tiling, so a workgroup's own chain
+// IS the launch: the 16 x 4 kernel above spends 33 of its 52 k cycles convolving four 128-channel slabs one after the other, each behind
+// its own DMA, at ~45 % of the matrix pipe's rate (profiles/r04_dw_stamps.txt), and fetches every input row 2.1 x (10 halo rows per 4).
+// This form:
+//   * HALF an image (16 columns x 8 rows) x ALL channels per workgroup: 11 real input rows per 8 (1.375 x), no column halo at all -- the
+//     columns left / right of the map and the rows above / below it are ZERO PIXELS THAT LIVE IN LDS (two per row, whole rows outside the
+//     map), written once per workgroup; an out-of-map lane of a B fragment reads the zero pixel of its row;
+//   * 64-channel slabs through a THREE-stage LDS-DMA ring (input rows + the slab's 49 taps: 38.5 KB per stage): slab s + 2 is requested
+//     when slab s starts, so a slab has two conv periods to land and only the first one is waited for;
+//   * a wave owns ONE channel octet of every slab and FOUR output row pairs: each tap fragment (A operand, built by VALU) feeds four
+//     MFMAs instead of two, and the six distinct 4-row B fragments of a column shift feed eight MFMAs (row pairs p and p + 2 share
+//     rows 2 p + 4 .. 2 p + 7): 0.75 LDS reads per MFMA, so the loop is bound by the matrix pipe, not by the LDS port (256 B / clk);
+//   * the accumulators of all slabs (128 registers at C = 512) stay in registers; LayerNorm statistics in one round as above; the
+//     normalised half image (128 KB at C = 512) is staged in LDS once -- the ring is dead by then -- and leaves as 1 KB rows.
+// LDS image of a stage: pixel slot P = r * 18 + cc (r: 14 halo rows, cc: 16 columns + zero pixels 16 / 17), 128 B per pixel = 8 slots
+// of 16 B (one channel octet each); octet o of column c sits in slot o ^ ((c >> 1) & 7) and an out-of-map column c reads zero pixel
+// 16 + (c & 1) at the slot its own c asks for: the 16 lanes of every ds_read_b128 lane group (8 columns of two adjacent rows) then hit
+// 16 different 16-byte bank groups for all seven column shifts (enumerated: scripts/probes/dw_tall_swizzle.py).  Taps: 128 B per tap,
+// 16-byte chunk c of filter row kh stored at chunk c ^ kh (the A lanes of a ds_read_u16 come from up to seven filter rows).
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int NS, int J, bool NOMFMA = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= 2 x real rows + 7); NOMFMA: timing ablation (wrong results)
+__global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
+                                                                 const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                                 const float* __restrict__ lnb, half_t* __restrict__ y, int H, float eps) {
+    constexpr int C = 64 * NS, W = 16, TH = 8, NP = TH / 2, IH = TH + 6, PITCH = 18, ROWB = PITCH * 128;
+    constexpr int IN_BYTES = IH * ROWB, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024, NST = 3;   // PAD_OFF: 1 KB, target of the padding DMA instructions
+    constexpr int OUT_BYTES = 128 * C * 2;                     // the normalised tile, staged over the dead ring
+    constexpr int PAR_OFF = (OUT_BYTES > NST * STAGE ? OUT_BYTES : NST * STAGE), PAR_INS = (3 * C * 4 + 1023) / 1024;
+    constexpr int RED_OFF = PAR_OFF + PAR_INS * 1024;          // [2][8 waves][128 px] fp32
+    static_assert(RED_OFF + 2 * 8 * 128 * 4 <= 160 * 1024, "LDS");
+    static_assert(PAR_INS <= 8, "one parameter DMA instruction per wave");
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
+    const float* par_s = reinterpret_cast<const float*>(dsm + PAR_OFF);
+    float* red_s = reinterpret_cast<float*>(dsm + RED_OFF);
+    float* red2_s = red_s + 8 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tpi = H / TH;
+    const int bid = xcd_chunk(blockIdx.x, gridDim.x);
+    const int b = bid / tpi, h0 = (bid - b * tpi) * TH;
+    const half_t* xb = x + (long)b * H * W * C;
+    // halo rows r = 0 .. 13 are image rows h0 - 3 + r; the real ones are rlo .. rhi
+    const int rlo = h0 >= 3 ? 0 : 3 - h0, rhi = min(IH - 1, H - 1 - (h0 - 3)), nreal = rhi - rlo + 1;
+    GP_DWT_MARK(0);
+
+    // ---- DMA plan.  ALL LDS-DMA is issued by waves 0-3 (one per SIMD): an LDS-DMA instruction holds its wave for 100-250 cycles (the CU's
+    //      address path takes 16 cycles per KB and every loading wave queues behind the others), cycles in which that wave issues no MFMA;
+    //      the hardware favours the older wave of a SIMD, so waves 0-3 finish their MFMAs ~700 cycles before waves 4-7 anyway and used to
+    //      spend them at the slab barrier (profiles/r06_dw_tall_stamps.txt).  Instruction slots i = wave + 4 j of a slab: 2 x nreal input
+    //      half rows, then 7 KB of taps, then padding.  First thing in the kernel: everything else runs under the first slabs' latency.
+    const bool loader = wave < 4;
+    auto slot_plan = [&](int i, unsigned long long& sb, unsigned& vo, unsigned& ds) {     // i: scalar slot index of a slab's DMA list
+        if (i < 2 * nreal) {
+            const int r = rlo + (i >> 1), cc = (i & 1) * 8 + (lane >> 3), o = (lane & 7) ^ ((cc >> 1) & 7);
+            sb = (unsigned long long)xb;
+            vo = (unsigned)((((h0 - 3 + r) * W + cc) * C + o * 8) * 2);
+            ds = (unsigned)((r * PITCH + (i & 1) * 8) * 128);
+        } else if (i < 2 * nreal + 7) {
+            const int t7 = i - 2 * nreal, tap = min(t7 * 8 + (lane >> 3), 48), kh = (tap * 37) >> 8, ch = (lane & 7) ^ kh;   // tap / 7 for tap < 56
+            sb = (unsigned long long)wt;
+            vo = (unsigned)((tap * C + ch * 8) * 2);
+            ds = (unsigned)(TAP_OFF + t7 * 1024);
+        } else {
+            sb = (unsigned long long)xb;
+            vo = (unsigned)((lane & 15) * 16);
+            ds = PAD_OFF;
+        }
+    };
+    // slab 0 and the parameters by ALL eight waves, first thing in the kernel (the launch is one round of workgroups: nothing hides this
+    // latency); slabs 1 and 2 follow from the loading waves behind the first barrier
+    if (wave < PAR_INS) {
+        const int f = (wave * 64 + lane) * 4;
+        const float* src = f < C ? bias + f : (f < 2 * C ? lnw + (f - C) : lnb + (f - 2 * C));
+        glds16_n(f < 3 * C ? (const void*)src : (const void*)gp_zero_page_tu, __builtin_amdgcn_readfirstlane(lds0 + PAR_OFF + wave * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < (J + 1) / 2; ++j) {
+        const int i = wave + 8 * j;
+        if (i < 2 * nreal + 7) {
+            unsigned long long sb; unsigned vo, ds;
+            slot_plan(i, sb, vo, ds);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+            glds16_sv((const void*)(((unsigned long long)hi << 32) | lo), vo, __builtin_amdgcn_readfirstlane(lds0 + ds));
+        }
+    }
+    unsigned voff[J];
+    unsigned slo[J], shi[J], sdst[J];      // wave-uniform source base of slab 0 (+ 128 bytes per slab: input and taps alike; padding re-reads input row 0) and LDS target
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        unsigned long long sb; unsigned ds;
+        slot_plan((wave & 3) + 4 * j, sb, voff[j], ds);
+        slo[j] = __builtin_amdgcn_readfirstlane((unsigned)sb);
+        shi[j] = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+        sdst[j] = __builtin_amdgcn_readfirstlane(lds0 + ds);
+    }
+    auto issue1 = [&](int s, int j) {      // DMA instruction j of slab s (s, j compile-time at every call site)
+        const unsigned long long sbu = (((unsigned long long)shi[j] << 32) | slo[j]) + (unsigned)(s * 128);
+        glds16_sv((const void*)sbu, voff[j], sdst[j] + (s % NST) * STAGE);
+    };
+    auto issue = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) issue1(s, j);
+    };
+    GP_DWT_MARK(1);
+
+    // ---- zero pixels (two per halo row) and the halo rows outside the map, all stages: written once, never touched by the DMA
+    {
+        const int r = tid >> 4, u = tid & 15;
+        if (r < IH) {
+#pragma unroll
+            for (int st = 0; st < NST; ++st) *reinterpret_cast<uint4*>(dsm + st * STAGE + (r * PITCH + 16) * 128 + u * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+        const int nbad = IH - nreal;                           // <= 6 rows of 128 16-byte units (the 16 real pixel slots)
+        for (int rr = tid >> 7; rr < nbad; rr += 4) {
+            const int rz = rr < rlo ? rr : rhi + 1 + (rr - rlo);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) *reinterpret_cast<uint4*>(dsm + st * STAGE + rz * ROWB + (tid & 127) * 16) = uint4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- lane roles (as dwconv7_ln_mfma_kernel): B / D column n = pixel column, q = input row of the K block; A lane: row (ar, ac), K chunk q
+    const int n = lane & 15, q = lane >> 4;
+    const int ar = n >> 3, ac = n & 7;
+    unsigned sw[7];       // byte offset of this lane's B slot for column shift kw (row block 0): row q, column n + kw - 3
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+        const int c = n + kw - 3;
+        const int cc = (unsigned)c < 16u ? c : 16 + (c & 1);
+        sw[kw] = (unsigned)(q * ROWB + cc * 128 + (((wave ^ (c >> 1)) & 7) << 4));
+    }
+    const int kh0 = q - ar, kh1 = q + 4 - ar;
+    const int kh0c = kh0 < 0 ? 0 : kh0, kh1c = kh1 > 6 ? 6 : kh1;
+    const unsigned woff0 = (unsigned)(TAP_OFF + kh0c * 7 * 128 + ((wave ^ kh0c) << 4) + ac * 2);
+    const unsigned woff1 = (unsigned)(TAP_OFF + kh1c * 7 * 128 + ((wave ^ kh1c) << 4) + ac * 2);
+    unsigned mk0[4], mk1[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        mk0[v] = (kh0 >= 0 && v == (ac >> 1)) ? 0xffffffffu : 0u;
+        mk1[v] = (kh1 <= 6 && v == (ac >> 1)) ? 0xffffffffu : 0u;
+    }
+    const int sh = 16 * (ac & 1);
+    // D layout: lane (n, q), slab s, row pair pp: channels 64 s + 8 wave + 4 (q & 1) + {0..3} of pixel (row 2 pp + (q >> 1), column n)
+    const int rsel = q >> 1, cq = wave * 8 + (q & 1) * 4;
+    GP_DWT_MARK(2);
+
+    f32x4 acc[NS][NP];
+    union Frag { uint4 u; half8 h; };
+    Frag af[2][2], bf[2][6];                       // af[slot][blk]; bf[slot][row block rb / 2]: halo rows rb .. rb + 3, rb = 0, 2, .., 10; slot = (7 s + kw) & 1
+    unsigned wraw[7][2];                           // the 14 taps of this lane's A rows (filter rows kh0 / kh1, all column shifts): read once per slab
+    auto fetch = [&](const char* in_s, int kw, int slot) {
+#pragma unroll
+        for (int rb = 0; rb < 6; ++rb) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);
+    };
+    auto taps = [&](const char* in_s) {
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            wraw[kw][0] = *reinterpret_cast<const unsigned short*>(in_s + woff0 + kw * 128);
+            wraw[kw][1] = *reinterpret_cast<const unsigned short*>(in_s + woff1 + kw * 128);
+        }
+    };
+    auto build = [&](int kw, int slot) {
+        const unsigned u0 = wraw[kw][0] << sh, u1 = wraw[kw][1] << sh;
+        af[slot][0].u = uint4{u0 & mk0[0], u0 & mk0[1], u0 & mk0[2], u0 & mk0[3]};
+        af[slot][1].u = uint4{u1 & mk1[0], u1 & mk1[1], u1 & mk1[2], u1 & mk1[3]};
+    };
+    // ONE barrier per slab, in front of the MFMAs of its LAST column shift: by then every fragment of slab s is in registers (stage s is
+    // free: slab s + 3 goes into it) and the loading waves have seen slab s + 1 land (slab s + 2 stays in flight: every slab has two
+    // conv periods to land); behind it the operands of slab s + 1's first column shift are fetched under the eight MFMAs that are left,
+    // so that the matrix pipe does not drain at a slab boundary (a barrier FOLLOWED by the first LDS round trip cost ~700 cycles per slab)
+    auto publish = [&](auto sc) {                  // slab s is done being read by this wave; make slab s + 1 visible
+        constexpr int s = decltype(sc)::value;
+        if (loader) {
+            if constexpr (s + 2 < NS) {
+                if constexpr (J == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of slab s (and, s = -1, the zero fill)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (s + 3 < NS) {
+            if (loader) issue(s + 3);
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of slab 0 (and of the parameters)
+    GP_DWT_MARK(4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    GP_DWT_MARK(5);
+    taps(dsm);
+    fetch(dsm, 0, 0);
+    if (loader) {
+        if (NS > 1) issue(1);
+        if (NS > 2) issue(2);
+    }
+    build(0, 0);
+    static_for<0, NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const char* in_s = dsm + (s % NST) * STAGE;
+        {   // the bias is the accumulators' initial value
+            const float4 bv = *reinterpret_cast<const float4*>(par_s + s * 64 + cq);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) acc[s][pp] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        }
+        GP_DWT_MARK(6 + 4 * s);
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {           // operands one column shift ahead: the reads and the A-fragment VALU work of shift kw + 1 ride BETWEEN the MFMAs of shift kw
+            const int slot = (7 * s + kw) & 1;     //   (an MFMA holds the issue port for 8 of its 16 cycles: in program order behind it, 1-2 other instructions are free)
+            if (kw == 6 && s + 1 < NS) {
+                GP_DWT_MARK(8 + 4 * s);
+                publish(sc);
+                GP_DWT_MARK(9 + 4 * s);
+                const char* nx = dsm + ((s + 1) % NST) * STAGE;
+                taps(nx);                          // wraw is dead: build(6) ran with the MFMAs of shift 5
+                fetch(nx, 0, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kw + 1 < 7) { fetch(in_s, kw + 1, slot ^ 1); build(kw + 1, slot ^ 1); }
+            if constexpr (!NOMFMA) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp)
+                        acc[s][pp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][blk].h, bf[slot][pp + 2 * blk].h, acc[s][pp], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) acc[s][pp][0] += __builtin_bit_cast(float, af[slot][blk].u.x ^ bf[slot][pp + 2 * blk].u.x);   // keeps the operand work alive
+            }
+            if (kw + 1 < 7 && !NOMFMA) {
+                static_for<0, 8>([&](auto ic) {    // MFMA, a fragment read (the first six), one or two VALU instructions
+                    constexpr int i = decltype(ic)::value;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if constexpr (i < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (s + 1 < NS) build(0, (7 * (s + 1)) & 1);     // first A fragments of the next slab (its taps were requested behind the barrier)
+        GP_DWT_MARK(7 + 4 * s);
+    });
+
+    // ---- LayerNorm statistics (one round), normalise, stage, store
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        float a = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a += acc[s][pp][e]; a2 = fmaf(acc[s][pp][e], acc[s][pp][e], a2); }
+        a += __shfl_xor(a, 16);
+        a2 += __shfl_xor(a2, 16);
+        if ((q & 1) == 0) { const int px = (2 * pp + rsel) * 16 + n; red_s[wave * 128 + px] = a; red2_s[wave * 128 + px] = a2; }
+    }
+    GP_DWT_MARK(40);
+    __syncthreads();      // also: every wave is done with the last slab's stage, which the output tile overlays
+    GP_DWT_MARK(41);
+    const float invC = 1.0f / C;
+    float rstd[NP], nmr[NP];     // (v - mean) rstd = fma(v, rstd, -mean rstd)
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int px = (2 * pp + rsel) * 16 + n;
+        float a = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) { a += red_s[w8 * 128 + px]; a2 += red2_s[w8 * 128 + px]; }
+        const float mean = a * invC;
+        rstd[pp] = rsqrtf(fmaxf(a2 * invC - mean * mean, 0.f) + eps);
+        nmr[pp] = -mean * rstd[pp];
+    }
+    char* out_s = dsm;
+    constexpr int cpp = C / 8;   // 16-byte chunks per pixel
+    half_t* yb = y + ((long)b * H + h0) * W * C;
+    // two halves (row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 gw = *reinterpret_cast<const float4*>(par_s + C + s * 64 + cq);
+            const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 64 + cq);
+            const int chunk = s * 8 + wave;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int pp = hf * 2 + p2;
+                half4 ov;
+                ov[0] = (_Float16)fmaf(fmaf(acc[s][pp][0], rstd[pp], nmr[pp]), gw.x, gb.x);
+                ov[1] = (_Float16)fmaf(fmaf(acc[s][pp][1], rstd[pp], nmr[pp]), gw.y, gb.y);
+                ov[2] = (_Float16)fmaf(fmaf(acc[s][pp][2], rstd[pp], nmr[pp]), gw.z, gb.z);
+                ov[3] = (_Float16)fmaf(fmaf(acc[s][pp][3], rstd[pp], nmr[pp]), gw.w, gb.w);
+                const int px = (2 * pp + rsel) * 16 + n;
+                *reinterpret_cast<half4*>(out_s + px * (C * 2) + ((chunk ^ n) << 4) + (q & 1) * 8) = ov;
+            }
+        }
+        GP_DWT_MARK(42 + 2 * hf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // not __syncthreads(): the first half's stores stay in flight
+        asm volatile("" ::: "memory");
+        GP_DWT_MARK(43 + 2 * hf);
+#pragma unroll 4
+        for (int i = tid; i < 64 * cpp; i += 512) {
+            const int px = hf * 64 + i / cpp, c = i % cpp;
+            const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
+            *reinterpret_cast<uint4*>(yb + (long)px * C + c * 8) = v;
+        }
+    }
+    GP_DWT_MARK(46);
+#ifdef GP_DW_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_DWT_MARK(47);
+#endif
+}
+
+template <int NS, int J, bool NOMFMA = false>
+void launch_dw7_tall(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B, int H,
+                     float eps, hipStream_t s) {
+    constexpr int C = 64 * NS, STAGE = 14 * 18 * 128 + 8 * 1024, OUTB = 128 * C * 2;
+    constexpr int PAR_OFF = (OUTB > 3 * STAGE ? OUTB : 3 * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 128 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, NOMFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, NOMFMA>), dim3(B * (H / 8)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
+                       lnw, lnb, (half_t*)y, H, eps);
+}
+
 // ---------------------------------------------------------------------------- row LayerNorm
 // TI != T: fp32 input rows, fp16 output (dtype GP_F16 | GP_IN_F32: the fp32 residual stream of the fp16 mode enters the
 // downsample LayerNorm in fp32); a thread then loads its 8 elements as two 16-byte vectors
@@ -1271,6 +1619,12 @@ static long dw_mfma_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : -1l; }();
     return k >= 0 ? k : C == 512 ? 52 : C == 256 ? 33 : 0;
 }
+// fewest half-image workgroups that go to dwconv7_ln_tall_kernel (one workgroup per CU: below ~3/4 of the chip the 16 x 4 tiles fill it better);
+// GP_DW_TALL_MIN=<n>: A/B (a huge value switches the kernel off)
+static long dw_tall_min_wgs() {
+    static const long k = [] { const char* e = getenv("GP_DW_TALL_MIN"); return e ? atol(e) : 192l; }();
+    return k;
+}
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
     return on;
@@ -1297,7 +1651,25 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     gp_timing_label("dwconv%d_ln C%d %dx%d B%d", KS, C, H, W, B);
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
-    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && H % 4 == 0 && W % 16 == 0 &&
+    // 16-pixel-wide maps (ConvNeXt stage 2): half-image tiles, from dw_tall_min_wgs() workgroups up (act code 110 forces it, 111: its no-conv ablation)
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && W == 16 && H % 8 == 0 && (C == 128 || C == 256 || C == 512) &&
+        x != y && (dbg == 10 || (dbg == 11 && C == 512 && H <= 16) || (dbg == 0 && (long)B * (H / 8) >= dw_tall_min_wgs()))) {
+#ifdef GP_DW_STAMPS      // investigation builds only (the instantiation spills): act code 111 = no MFMAs, timing only
+        if (dbg == 11) launch_dw7_tall<8, 8, true>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+        else
+#endif
+        if (H <= 16) {
+            if (C == 128) launch_dw7_tall<2, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+            else if (C == 256) launch_dw7_tall<4, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+            else launch_dw7_tall<8, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+        } else {
+            if (C == 128) launch_dw7_tall<2, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+            else if (C == 256) launch_dw7_tall<4, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+            else launch_dw7_tall<8, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+        }
+        GP_LAUNCH_CHECK("gp_dwconv_ln");
+    }
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && dbg < 10 && H % 4 == 0 && W % 16 == 0 &&
         (C == 128 || C == 256 || C == 512) && (long)B * (H / 4) * (W / 16) >= dw_mfma_min_wgs(C)) {
         if (C == 128) launch_dw7_mfma<1, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);
         else if (C == 256) launch_dw7_mfma<2, 1>(x, wt, bias, ln_w, ln_b, y, B, H, W, C, eps, s, dbg);

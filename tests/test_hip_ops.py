@@ -665,6 +665,35 @@ def test_dwconv_ln_fp16_kernels_by_grid_size(C, H, KS, B, offset):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("C,H,B,offset", [(512, 16, 3, 0.0), (512, 16, 128, 0.0), (256, 16, 5, 0.0), (128, 16, 2, 0.0), (512, 8, 2, 0.0),
+                                          (512, 32, 2, 0.0), (256, 24, 1, 0.0), (512, 16, 7, 5.0)])
+def test_dwconv_ln_tall_tiles(C, H, B, offset):
+    """dwconv7_ln_tall_kernel (round 6: 16 x 8 tiles of 16-pixel-wide maps, zero pixels in LDS instead of a halo, three-stage slab ring):
+    forced with act code 110 at grids the routing would not send it (it takes over from 192 half-image workgroups), against the fp32
+    reference and against the 16 x 4 / strip kernels on the same input; H = 8 (one tile, zero rows above AND below), H = 16 (the
+    product shape), H = 24 / 32 (interior tiles with 14 real halo rows: the five-instruction DMA plan); offset 5: |mean| ~ 50 std."""
+    o = ops()
+    dt = torch.float16
+    W = 16
+    x = q(rnd(B, C, H, W, seed=140), dt)
+    w = q(rnd(C, 1, 7, 7, seed=141, scale=(0.02 if offset else 1.0) / 7), dt)
+    b = rnd(C, seed=142, scale=0.1) + offset
+    lw, lb = 1 + 0.1 * rnd(C, seed=143), 0.1 * rnd(C, seed=144)
+    ref = F.layer_norm(F.conv2d(x, w, b, padding=3, groups=C).permute(0, 2, 3, 1), (C,), lw, lb, 1e-6)
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    wd = w.reshape(C, 49).t().contiguous().to("cuda", dt)
+    out = torch.zeros(B, H, W, C, dtype=dt, device="cuda")
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out, 7, act=110)
+    assert rel_err(out, ref) < (2 * TOL[dt] if offset else TOL[dt]), rel_err(out, ref)
+    old = torch.zeros_like(out)
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), old, 7)       # below 192 workgroups the routing takes the older kernels
+    if B * (H // 8) < 192:
+        assert float((out.float() - old.float()).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
+    out2 = torch.zeros_like(out)      # bitwise repeatable
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2, 7, act=110)
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("C", [128, 256, 512])
 def test_layernorm(dt, C):
