@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GP_LIB_PATH: A/B runs of two builds on one box (scripts/race_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("GP_LIB_PATH") or os.path.join(_HERE, "libgivepose_hip.so")
 
-ABI_VERSION = 321        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
+ABI_VERSION = 322        # include/givepose_hip.h GP_ABI_VERSION: gp_gemm_desc layout (checked against gp_version() at load)
 GP_F32, GP_F16, GP_F64 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_LRELU = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_LRELU, EPI_SCALE_RES, EPI_RES_RELU, EPI_LNFOLD_GELU = 0, 1, 2, 3, 4, 5, 6
@@ -50,6 +50,7 @@ PROTOTYPES = {
     "gp_convnext_mlp": ([_P] * 8 + [c_long, c_int, c_int, _P], c_int),
     "gp_convnext_stem": ([_P] * 6 + [c_int] * 4 + [c_float, c_int, _P], c_int),
     "gp_dwconv_ln": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, c_long, c_int, _P], c_int),
+    "gp_dwconv_ln_groups": ([_P] * 6 + [c_int] * 5 + [c_float, c_int, _P, c_int, _P], c_int),
     "gp_dwconv7_raw_stats": ([_P] * 5 + [c_int] * 5 + [_P], c_int),
     "gp_layernorm": ([_P] * 4 + [c_long, c_int, c_float, c_int, c_int, _P], c_int),
     "gp_groupnorm_chunks": ([c_int, c_int], c_int),

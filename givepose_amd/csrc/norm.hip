@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ lnw,
                                                         const float* __restrict__ lnb, T* __restrict__ y, int H,
-                                                        int W, int C, float eps, int act, long n_pixels, long pl) {
+                                                        int W, int C, float eps, int act, long n_pixels, long pl,
+                                                        const int* __restrict__ grp = nullptr) {
     constexpr int VEC = Vec16<T>::N, R = KS / 2;
     __shared__ float red[4 * PPT];
     const int CT = C / VEC, PG = 256 / CT;
@@ -95,8 +96,17 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
     const long strip = (long)blockIdx.x * PG + pg;
     const long pix0 = strip * PPT;
     const bool valid = pix0 < n_pixels;
-    const int w0 = (int)(pix0 % W);
-    const long t = pix0 / W;
+    // grp (gp_dwconv_ln_groups): the output is the quarter-size flat prefix list of SEVERAL batches behind one another (H W / 4 rows per
+    // crop); output row j of a crop whose batch starts at crop g reads the flat full-resolution pixel j + 3 g (H W / 4) -- row j - g q of
+    // that batch's own flat list.  g is clamped to [0, crop]: whatever the table holds, the source stays inside x.
+    long pix0s = pix0;
+    if (grp != nullptr && valid) {
+        const long q = (long)H * W / 4, c = pix0 / q;
+        const long g = min((long)max(grp[c], 0), c);
+        pix0s += 3 * g * q;
+    }
+    const int w0 = (int)(pix0s % W);
+    const long t = pix0s / W;
     const int h = (int)(t % H);
     const long b = t / H;
     float acc[PPT][VEC];
@@ -1708,6 +1718,33 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     else { if (KS == 7) GP_DW(float, 7, 8); else GP_DW(float, 3, 8); }
 #undef GP_DW
     GP_LAUNCH_CHECK("gp_dwconv_ln");
+}
+
+extern "C" int gp_dwconv_ln_groups(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b, void* y, int B,
+                                   int H, int W, int C, int KS, float eps, int act, const int* crop_group_start, int dtype, void* stream) {
+    GP_REQUIRE(x && wt && bias && ln_w && ln_b && y && crop_group_start, "gp_dwconv_ln_groups: null pointer");
+    GP_REQUIRE(dtype == GP_F32 || dtype == GP_F16, "gp_dwconv_ln_groups: bad dtype");
+    const int esz = dtype == GP_F16 ? 2 : 4;
+    GP_REQUIRE(ct_ok(C, esz) && C / (16 / esz) >= 16, "gp_dwconv_ln_groups: unsupported C=%d", C);
+    GP_REQUIRE(KS == 3 || KS == 7, "gp_dwconv_ln_groups: KS=%d unsupported (3 or 7)", KS);
+    GP_REQUIRE(B > 0 && W % 16 == 0 && H % 2 == 0 && x != y, "gp_dwconv_ln_groups: B=%d, W=%d %% 16, H=%d %% 2, y != x required", B, W, H);
+    GP_REQUIRE(act == GP_ACT_NONE || act == GP_ACT_GELU || act == GP_ACT_RELU || act == GP_ACT_LRELU, "gp_dwconv_ln_groups: bad act");
+    const long n_pixels = (long)B * H * W / 4;
+    const int CT = C / (16 / esz), PG = 256 / CT;
+    const long strips = (n_pixels + 7) / 8;
+    hipStream_t s = (hipStream_t)stream;
+    gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
+    gp_timing_label("dwconv%d_ln groups C%d %dx%d B%d", KS, C, H, W, B);
+    const bool narrow = dtype == GP_F16 && cdiv(strips, PG) < dw_narrow_below();
+    dim3 grid(narrow ? cdiv((n_pixels + 1) / 2, PG) : cdiv(strips, PG));
+#define GP_DWG(T, K, P) hipLaunchKernelGGL((dwconv_ln_kernel<T, K, P>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, 0l, crop_group_start)
+    if (dtype == GP_F16) {
+        if (narrow) { if (KS == 7) GP_DWG(half_t, 7, 2); else GP_DWG(half_t, 3, 2); }
+        else { if (KS == 7) GP_DWG(half_t, 7, 8); else GP_DWG(half_t, 3, 8); }
+    }
+    else { if (KS == 7) GP_DWG(float, 7, 8); else GP_DWG(float, 3, 8); }
+#undef GP_DWG
+    GP_LAUNCH_CHECK("gp_dwconv_ln_groups");
 }
 
 extern "C" int gp_dwconv7_raw_stats(const void* x, const void* wt, const float* bias, void* y, float* stats, int B, int H,

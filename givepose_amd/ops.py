@@ -403,6 +403,18 @@ def dwconv_ln(x, wt, bias, ln_w, ln_b, out, KS, eps=1e-6, act=ACT_NONE, n_pixels
     return out
 
 
+def dwconv_ln_groups(x, wt, bias, ln_w, ln_b, out, KS, crop_group_start, eps=1e-6, act=ACT_NONE):
+    """gp_dwconv_ln_groups: the quarter-size prefix rows of several batches in one launch; crop_group_start: int32 (B,) on the device."""
+    B, H, W_, C = x.shape
+    if crop_group_start.dtype != torch.int32 or crop_group_start.numel() < B or not crop_group_start.is_cuda:
+        raise RuntimeError("dwconv_ln_groups: crop_group_start must be a device int32 tensor with one entry per crop")
+    if out.numel() < B * H * W_ // 4 * C:
+        raise RuntimeError("dwconv_ln_groups: output too small")
+    check(_L().gp_dwconv_ln_groups(_ptr(_contig(x, "x")), _ptr(wt), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, H, W_, C, KS, eps, act,
+                                   _ptr(crop_group_start), dtype_code(x.dtype), _stream()), "gp_dwconv_ln_groups")
+    return out
+
+
 def dwconv7_raw_stats(x, wt, bias, out, stats):
     """Depth-wise 7x7 + bias only; per-pixel slab moments of the rounded output -> stats (pixels, 2, C/128) fp32."""
     B, H, W_, C = x.shape

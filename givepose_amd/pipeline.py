@@ -37,3 +37,28 @@ class FramePipeline:
         out = self.net.forward_device(static, self.dev)
         rt, size = pred_rt(out, pred_scale)
         return rt, size, out
+
+    @torch.no_grad()
+    def run_frames(self, frames_u8, masks_u8, bboxes, cat_ids, cam_K, mean_shapes, full_imgs):
+        """The detections of SEVERAL frames in ONE launch sequence (the loop body of evaluation/evaluate.py:89-126 for F frames at once;
+        every frame keeps the DCNv3 prefix coupling of its own `forward`: PoseNet.forward_device(groups=...)).
+        frames (F,H,W,3) uint8; masks_u8 / bboxes / cat_ids / mean_shapes: per-frame lists (n_f,H,W) / (n_f,4) / (n_f,) / (n_f,3); cam_K (3,3)
+        or (F,3,3); full_imgs (F,3,S,S).  Returns (pred_RT (N,4,4), pred_size (N,3), out dict, sizes) with N = sum n_f, frame-major."""
+        sizes = [len(b) for b in bboxes]
+        n, F = sum(sizes), len(sizes)
+        static = self.net.static_inputs(n, self.dev, ragged=True)
+        frame_of = [f for f, k in enumerate(sizes) for _ in range(k)]
+        allmasks = torch.cat([torch.as_tensor(m) for m in masks_u8], 0)
+        allboxes = np.concatenate([np.asarray(b).reshape(-1, 4) for b in bboxes], 0)
+        self.cropper(torch.as_tensor(frames_u8), allmasks, frame_of, list(range(n)), allboxes, out=static)
+        K = torch.as_tensor(cam_K, dtype=torch.float32)
+        static["cam_K"].copy_(K.expand(n, 3, 3) if K.dim() == 2 else K[frame_of])
+        static["mean_size"].copy_(torch.cat([torch.as_tensor(m, dtype=torch.float32).reshape(-1, 3) for m in mean_shapes], 0))
+        data = dict(static)
+        data["full_img"] = torch.as_tensor(full_imgs, dtype=torch.float32).to(self.dev)[frame_of].contiguous()
+        cats = np.concatenate([np.asarray(c).reshape(-1) for c in cat_ids])
+        data["one_hot"] = torch.from_numpy(np.eye(self.cats, dtype=np.float32)[cats]).to(self.dev)
+        pred_scale = self.scale_net(data, self.dev, "test")
+        out = self.net.forward_device(static, self.dev, groups=sizes)
+        rt, size = pred_rt(out, pred_scale)
+        return rt, size, out, sizes

@@ -100,7 +100,8 @@ class PoseNet(nn.Module):
             # the A/B build with packed fp32 VALU ops: v_pk_fma_f32 results of one kernel's waves come out wrong beside another
             # kernel's MFMA stream on the same SIMD -- only strictly serial launches are safe with it
             raise RuntimeError("GP_PACKED_FP32=1 builds must not keep batches in flight (inflight > 1)")
-        self._plans = {}          # (B, slot) -> buffers / graph
+        self._plans = OrderedDict()   # (B, slot, ragged) -> buffers / graph, least recently used first
+        self.max_plans = int(os.environ.get("GP_MAX_PLANS", "12"))   # per model: a caller with B in 1 .. 48 would otherwise keep 48 buffer sets + graphs
         self._streams = {}        # slot -> dedicated stream of the hipGraph path
         self.eval()
 
@@ -118,7 +119,7 @@ class PoseNet(nn.Module):
                     lib.gp_graph_destroy(plan["graph"])
                     plan["graph"] = None
         self._packed = None
-        self._plans = {}
+        self._plans = OrderedDict()
 
     def __del__(self):
         try:
@@ -266,9 +267,32 @@ class PoseNet(nn.Module):
         return W
 
     # ------------------------------------------------------------------ buffers
-    def _plan(self, B, device, slot=0):
-        plan = self._plans.get((B, slot))
+    # total crop counts a multi-frame (ragged) forward is padded to: a few graph shapes instead of one per total
+    RAGGED_BUCKETS = (8, 16, 24, 32, 48, 64, 96, 128)
+
+    @classmethod
+    def ragged_bucket(cls, n):
+        for b in cls.RAGGED_BUCKETS:
+            if n <= b:
+                return b
+        return (n + 63) // 64 * 64
+
+    def _evict_plans(self, keep):
+        """Least-recently-used plans beyond max_plans go: the device is synchronised first (a slot's stream may still run the graph
+        whose exec holds raw pointers into the buffers), the graph exec destroyed, then the tensors released."""
+        while len(self._plans) > max(self.max_plans, 1):
+            key = next(k for k in self._plans if k != keep)
+            torch.cuda.synchronize()
+            plan = self._plans.pop(key)
+            if plan.get("graph") is not None:
+                _lib.load().gp_graph_destroy(plan["graph"])
+                plan["graph"] = None
+
+    def _plan(self, B, device, slot=0, ragged=False):
+        key = (B, slot, bool(ragged))
+        plan = self._plans.get(key)
         if plan is not None:
+            self._plans.move_to_end(key)
             return plan
         T, cfg = self.compute_dtype, self.cfg
         R, S = cfg.out_res, cfg.img_size
@@ -324,8 +348,19 @@ class PoseNet(nn.Module):
         buf["fc1"] = e(B, 2048)
         buf["hh"], buf["hz"] = f(B, 256), f(B, 256)
         buf["rot6d"], buf["pred_t"], buf["rot_allo"], buf["rot_ego"], buf["trans"] = f(B, 6), f(B, 3), f(B, 9), f(B, 9), f(B, 3)
-        plan = {"buf": buf, "graph": None, "warm": False}
-        self._plans[(B, slot)] = plan
+        plan = {"buf": buf, "graph": None, "warm": False, "ragged": bool(ragged)}
+        if ragged:
+            # crop -> first crop of its batch (gp_dwconv_ln_groups); rewritten before every launch, the pointer is what the graph holds.
+            # Padding crops (beyond the real ones) are batches of their own and keep benign inputs: zero image, identity camera.
+            buf["grp"] = torch.arange(B, dtype=torch.int32, device=device)
+            buf["grp_host"] = torch.arange(B, dtype=torch.int32).pin_memory()
+            for k in ("roi_img", "roi_mask", "roi_coord_2d", "bbox_center", "mean_size"):
+                buf[k].zero_()
+            buf["roi_wh"].fill_(1.0)
+            buf["resize_ratio"].fill_(1.0)
+            buf["cam_K"].copy_(torch.eye(3, device=device).expand(B, 3, 3))
+        self._plans[key] = plan
+        self._evict_plans(key)
         return plan
 
     # ------------------------------------------------------------------ launch sequence
@@ -509,12 +544,27 @@ class PoseNet(nn.Module):
                     ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "fold_w"], W[q + "fold_b"], buf[f"e_proj{li}"].view(-1, 256))
                 else:
                     ops.gemm(prev.view(-1, 256), W[q + "fold_w"], buf[f"e_proj{li}"].view(-1, 256), bias=W[q + "fold_b"])
+                if plan.get("ragged"):
+                    # several batches of ANY sizes (the detections of several frames) in one launch each: output row j of the quarter-size
+                    # offset / mask grid IS global output pixel j whatever the batch structure -- only the dw3x3 branch has to know that
+                    # the rows of a batch are the flat prefix of THAT batch's full-resolution pixels (device table buf["grp"]); the
+                    # conv1x1 in front of it runs over every crop's rows (the prefixes lie somewhere in them)
+                    if li == 0:
+                        ops.pointwise_k3(buf["nocs_nhwc4"], W[q + "conv_w"], W[q + "conv_b"], xin.view(-1, 256))
+                    else:
+                        ops.gemm(prev.view(-1, 256), W[q + "conv_w"], xin.view(-1, 256), bias=W[q + "conv_b"])
+                    ops.dwconv_ln_groups(xin, W[q + "dw_w"], W[q + "dw_b"], W[q + "ln_w"], W[q + "ln_b"], buf[f"e_x1{li}"], 3, buf["grp"], act=ACT_GELU)
+                    ops.gemm(buf[f"e_x1{li}"], W[q + "om_w"], buf[f"e_om{li}"], bias=W[q + "om_b"])
+                    ops.dcnv3_forward_into(buf[f"e_proj{li}"], buf[f"e_om{li}"], buf[f"e_om{li}"][:, 72:], buf[f"e_g{li}"], 3, 2, 1, 1, 4, 64, 1.0,
+                                           off_ld=OM_LD, mask_ld=OM_LD, mask_is_logits=True)
                 # the offset / mask branch and the gather see ONE batch's flat prefix at a time (grouped launches: a group =
                 # one batch of dcn_couple crops; otherwise the whole forward is the one group)
                 Bg = self.dcn_couple if (self.dcn_couple and B > self.dcn_couple) else B
-                if B % Bg:
+                if plan.get("ragged"):
+                    Bg = B + 1          # (no per-batch launches: range() below is empty)
+                if B % Bg and not plan.get("ragged"):
                     raise ValueError(f"batch {B} is not a multiple of dcn_couple = {Bg}")
-                for g0 in range(0, B, Bg):
+                for g0 in range(0, B if not plan.get("ragged") else 0, Bg):
                     gs = slice(g0, g0 + Bg)
                     nq = Bg * ro * ro      # rows of the full-resolution offset/mask grid the gather consumes
                     # + one image row of halo for the 3x3 depth-wise conv; rounded up to 16 rows so that the few-crop case (88 / 296 rows at one crop) takes the
@@ -583,8 +633,13 @@ class PoseNet(nn.Module):
         return self._streams[slot]
 
     @torch.no_grad()
-    def forward_device(self, data, device="cuda", slot=0, wait=True):
+    def forward_device(self, data, device="cuda", slot=0, wait=True, groups=None):
         """Runs the path and returns views of the static output buffers, all on the device (no D->H sync).
+
+        groups: a list of batch sizes summing to the crop count -- the crops are the concatenated inputs of len(groups) separate
+        ``forward`` calls of the reference (the detections of several frames, evaluation/evaluate.py:89-114) and every batch keeps its own
+        DCNv3 prefix coupling, in ONE launch sequence whose length does not depend on the number of batches.  The
+        total is padded to a bucket size (RAGGED_BUCKETS) with one-crop batches so that a few hipGraphs serve every frame set.
 
         slot / wait: independent batches in flight.  Every slot owns its buffers, hipGraph and stream (the packed
         weights are shared); with ``wait=False`` the calling stream is not made to wait for the result, so forwards
@@ -600,6 +655,15 @@ class PoseNet(nn.Module):
         if self._packed is None:
             self._pack(device)
         B = data["roi_img"].shape[0]
+        n_real = B
+        if groups is not None:
+            groups = [int(g) for g in groups]
+            if not groups or min(groups) < 1 or sum(groups) != B:
+                raise ValueError(f"groups {groups} must be positive batch sizes summing to the {B} crops")
+            if self.cfg.nocsmap_encoder != "conv" or self.cfg.use_dcn != "dcnv3":
+                groups = None           # nothing couples the crops of a batch: the plain forward IS the multi-frame forward
+            else:
+                B = self.ragged_bucket(n_real)
         cur = torch.cuda.current_stream()
         if self.use_graph:
             # hipGraph capture is not permitted on the legacy default stream: the graph path owns a stream (per slot)
@@ -610,14 +674,26 @@ class PoseNet(nn.Module):
         else:
             run_stream = cur
         with torch.cuda.stream(run_stream):
-            plan = self._plan(B, device, slot)          # a new plan's buffers belong to the stream that will use them
+            plan = self._plan(B, device, slot, ragged=groups is not None)   # a new plan's buffers belong to the stream that will use them
             buf = plan["buf"]
             for k in self._INPUT_KEYS:
                 src = data[k]
                 if src.data_ptr() != buf[k].data_ptr():
-                    buf[k].copy_(src.reshape(buf[k].shape), non_blocking=True)
+                    buf[k][:n_real].copy_(src.reshape((n_real,) + tuple(buf[k].shape[1:])), non_blocking=True)
                     if src.is_cuda and run_stream is not cur:
                         src.record_stream(run_stream)   # the caller may free `src` while this copy is still queued
+            if groups is not None:
+                gh = buf["grp_host"]
+                if plan.get("grp_event") is not None:
+                    plan["grp_event"].synchronize()     # the previous launch's table copy has left the pinned buffer
+                i = 0
+                for g in groups:
+                    gh[i:i + g] = i
+                    i += g
+                gh[n_real:] = torch.arange(n_real, B, dtype=torch.int32)
+                buf["grp"].copy_(gh, non_blocking=True)
+                plan["grp_event"] = torch.cuda.Event()
+                plan["grp_event"].record(run_stream)
             if self.use_graph and plan["warm"]:
                 lib = _lib.load()
                 sp = ctypes.c_void_p(run_stream.cuda_stream)
@@ -638,10 +714,12 @@ class PoseNet(nn.Module):
                 plan["warm"] = True
         if run_stream is not cur and wait:
             cur.wait_stream(run_stream)
-        return {"rot": buf["rot_ego"].view(B, 3, 3), "trans": buf["trans"], "size": buf["size"], "mask": buf["mask_out"],
-                "nocs_coor": buf["nocs_nchw"], "ivfc_coor": buf["ivfc_nchw"], "rot6d": buf["rot6d"], "pred_t": buf["pred_t"],
-                "rot_allo": buf["rot_allo"].view(B, 3, 3), "feat": buf.get(f"x{len(self.cfg.convnext_dims) - 1}"),
-                "feat_cat": buf["feat_cat"]}
+        n = n_real
+        feat = buf.get(f"x{len(self.cfg.convnext_dims) - 1}")
+        return {"rot": buf["rot_ego"].view(B, 3, 3)[:n], "trans": buf["trans"][:n], "size": buf["size"][:n], "mask": buf["mask_out"][:n],
+                "nocs_coor": buf["nocs_nchw"][:n], "ivfc_coor": buf["ivfc_nchw"][:n], "rot6d": buf["rot6d"][:n], "pred_t": buf["pred_t"][:n],
+                "rot_allo": buf["rot_allo"].view(B, 3, 3)[:n], "feat": None if feat is None else feat[:n],
+                "feat_cat": buf["feat_cat"][:n]}
 
     # ---- sub-sequences of the path, eager, for the per-module golden vectors (tests/test_hip_modules.py); every one
     #      runs exactly the launches forward_device runs for that module, on the same plan buffers
@@ -703,18 +781,22 @@ class PoseNet(nn.Module):
         self._seq_pnp(B, plan)
         return buf["rot6d"].clone(), buf["pred_t"].clone()
 
-    def static_inputs(self, B, device="cuda", slot=0):
-        """The plan's device-resident input buffers (fill these to skip the per-call H->D copies)."""
+    def static_inputs(self, B, device="cuda", slot=0, ragged=False):
+        """The plan's device-resident input buffers (fill these to skip the per-call H->D copies).  ragged: the buffers of the
+        multi-frame plan that serves B crops (its first B rows; forward_device(..., groups=...) finds them in place)."""
         if self._packed is None:
             self._pack(torch.device(device))
+        if ragged and self.cfg.nocsmap_encoder == "conv" and self.cfg.use_dcn == "dcnv3":
+            buf = self._plan(self.ragged_bucket(B), torch.device(device), slot, ragged=True)["buf"]
+            return {k: buf[k][:B] for k in self._INPUT_KEYS}
         return {k: self._plan(B, torch.device(device), slot)["buf"][k] for k in self._INPUT_KEYS}
 
     @torch.no_grad()
-    def forward(self, data, device="cuda", do_loss=False, pred_scale=None):
-        """Reference signature (network/PoseNet.py:173).  ``do_loss`` (training) is out of scope."""
+    def forward(self, data, device="cuda", do_loss=False, pred_scale=None, groups=None):
+        """Reference signature (network/PoseNet.py:173).  ``do_loss`` (training) is out of scope.  groups (extension): see forward_device."""
         if do_loss:
             raise NotImplementedError("training path (do_loss=True) is out of scope for the inference build")
-        out = self.forward_device(data, device)
+        out = self.forward_device(data, device, groups=groups)
         # the reference returns rot as a CPU tensor (pose_from_pred_centroid_z.py:157) and fresh tensors
         return {"rot": out["rot"].cpu(), "trans": out["trans"].clone(), "size": out["size"].clone(),
                 "mask": out["mask"].clone(), "nocs_coor": out["nocs_coor"].clone(), "ivfc_coor": out["ivfc_coor"].clone()}

@@ -50,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 321 /* round 5: gp_gemm_desc.gn_rows + gp_gemm_gn_rows (321); gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
+#define GP_ABI_VERSION 322 /* round 6: + gp_dwconv_ln_groups (322); 321 = round 5: gp_gemm_desc.gn_rows + gp_gemm_gn_rows (321); gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -221,6 +221,15 @@ int gp_convnext_stem(const float* img, const float* w, const float* b, const flo
 int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b,
                  void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
                  void* stream);
+
+/* The same for SEVERAL batches in one launch (the detections of several frames, each frame one `PoseNet.forward` of the reference:
+ * evaluation/evaluate.py:89-114): y (B*H*W/4, C) = for every crop the quarter-size flat prefix rows DCNv3 consumes
+ * (ops_dcnv3/modules/dcnv3.py:318-356 hands the CUDA kernel offsets of an (N,H,W) grid that it reads as (N,H/2,W/2): SURVEY.md 0.3),
+ * where output row j of a crop whose batch starts at crop crop_group_start[crop] is the result at flat full-resolution pixel
+ * j + 3 * crop_group_start[crop] * H*W/4 of x -- i.e. every batch reads the prefix of ITS OWN flat pixel list.  crop_group_start:
+ * B int32 on the device (one table entry per crop; entries are clamped to [0, crop]).  W % 16 == 0, H even, y != x. */
+int gp_dwconv_ln_groups(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b, void* y, int B,
+                        int H, int W, int C, int KS, float eps, int act, const int* crop_group_start, int dtype, void* stream);
 
 /* ConvNeXt block front half with the LayerNorm deferred to the consuming GEMM (GP_EPI_LNFOLD_GELU): depth-wise 7x7
  * (pad 3, bias) only; y = conv output rounded to fp16, stats (B*H*W, 2, C/128) fp32 = per pixel the (sum, sum of

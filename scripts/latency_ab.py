@@ -24,7 +24,7 @@ for B in Bs:
                 net.forward_device(one, dev)
             torch.cuda.synchronize(dev)
             ts.append((time.perf_counter() - t0) / 50 * 1e3)
-        rot = net._plans[(B, 0)]["buf"]["rot6d"].float().cpu().clone()     # the 6-D logits: R itself is ill-conditioned for some crops
+        rot = net._plans[(B, 0, False)]["buf"]["rot6d"].float().cpu().clone()     # the 6-D logits: R itself is ill-conditioned for some crops
         if ref is None:
             ref = rot
         res[name] = (round(sorted(ts)[len(ts) // 2], 3), float((rot - ref).abs().max()))

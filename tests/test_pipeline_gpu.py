@@ -42,6 +42,38 @@ def test_frame_pipeline_matches_oracle_chain():
     assert np.abs(size.cpu().numpy() - ref_size).max() < 1e-4
 
 
+@pytest.mark.gpu
+def test_run_frames_equals_frame_by_frame():
+    """FramePipeline.run_frames (the detections of several frames in ONE launch sequence, per-frame DCNv3 coupling through
+    PoseNet.forward_device(groups=...)) against the one-frame pipeline called once per frame (itself checked against the oracle chain above)."""
+    from givepose_amd import PoseNet, PoseNetConfig, Scale_net, synth
+    from givepose_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(13)
+    H, W, sizes = 480, 640, (3, 1, 6, 2)
+    F = len(sizes)
+    frames = rng.integers(0, 256, (F, H, W, 3), dtype=np.uint8)
+    masks = [(rng.random((n, H, W)) > 0.5).astype(np.uint8) for n in sizes]
+    boxes = []
+    for n in sizes:
+        y1, x1 = rng.integers(0, 200, n), rng.integers(0, 300, n)
+        boxes.append(np.stack([y1, x1, y1 + rng.integers(60, 260, n), x1 + rng.integers(60, 320, n)], 1))
+    cats = [rng.integers(0, 6, n) for n in sizes]
+    shapes = [synth.MEAN_SIZES[c] for c in cats]
+    full = rng.standard_normal((F, 3, 256, 256)).astype(np.float32)
+    net = PoseNet(PoseNetConfig(), dtype=torch.float32, seed=0).cuda()
+    pipe = FramePipeline(net, Scale_net(feat_dim=24, seed=0).cuda())
+    rt, size, out, got_sizes = pipe.run_frames(frames, masks, boxes, cats, synth.REAL_INTRINSICS, shapes, full)
+    rt, size, mask = rt.clone(), size.clone(), out["mask"].clone()
+    assert list(got_sizes) == list(sizes) and rt.shape[0] == sum(sizes)
+    i = 0
+    for f, n in enumerate(sizes):
+        rt1, size1, out1 = pipe(frames[f], masks[f], boxes[f], cats[f], synth.REAL_INTRINSICS, shapes[f], full[f])
+        assert torch.equal(mask[i:i + n], out1["mask"])
+        assert float((rt[i:i + n] - rt1).abs().max()) < 1e-4 * max(1.0, float(rt1.abs().max())), f
+        assert float((size[i:i + n] - size1).abs().max()) < 5e-5, f
+        i += n
+
+
 def test_checkpoint_key_remap_cpu():
     """timm un-flattened names, HuggingFace names and a DataParallel prefix land on the registered names; junk is refused."""
     from givepose_amd import PoseNet
