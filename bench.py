@@ -361,9 +361,9 @@ def main():
                 ego_p90 = max(ego_p90, float(per[min(per.numel() - 1, int(0.9 * per.numel()))]))
                 d_allo = (gallo[j * B:(j + 1) * B] - o["rot_allo"].float().cpu().reshape(-1, 9)).abs().max(1).values
                 allo_median = max(allo_median, float(d_allo.sort().values[d_allo.numel() // 2]))
-                ratio = d_allo.double() / bnd
+                ratio = torch.nan_to_num(d_allo.double() / bnd, nan=1e9, posinf=1e9)      # bound 0 (a well-conditioned crop that moved far): a failure, and a finite number on the JSON line
                 explained = explained and bool((ratio <= 1.0).all())
-                worst_ratio = max(worst_ratio, float(ratio.max()))
+                worst_ratio = min(max(worst_ratio, float(ratio.max())), 1e9)
             del alone
             grouped_vs_alone = {"bitwise": bool(bit), "rot_median_over_crops": float(dmax[0]), "rot_max_over_crops": float(dmax[3]),
                                 "trans": float(dmax[1]), "size": float(dmax[2]), "batches_compared": G}
@@ -422,7 +422,7 @@ def main():
             line["invalid"] = why
             note("FAILED: " + why)
             if rank == 0:
-                print(json.dumps(line), flush=True)
+                print(json.dumps(line, allow_nan=False), flush=True)
             if coll:
                 barrier()
                 dist.destroy_process_group()
@@ -740,7 +740,7 @@ def main():
             "frame_by_frame_crops_per_s": (g("frames_grouped", "6_frames") or {}).get("frame_by_frame_crops_per_s"),
             "cpu_baseline_images_per_s": g("cpu_baseline", "value"),
             "cpu_cores": g("cpu_baseline", "cores")}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, allow_nan=False), flush=True)
     if coll:
         barrier()
         dist.destroy_process_group()

@@ -137,7 +137,12 @@ def main(argv=None):
         print(main.__doc__)
         return 2
     exp = _read_expected(argv[1] if len(argv) > 1 else os.path.join(root, EXPECTED_KEYS_FILE))
-    ck = torch.load(argv[0], map_location="cpu")
+    try:        # third-party checkpoints: never unpickle arbitrary objects just to diff key names
+        ck = torch.load(argv[0], map_location="cpu", weights_only=True)
+    except Exception as e:
+        print(f"cannot read {argv[0]} with weights_only=True ({type(e).__name__}: {e}).\n"
+              "If you trust the file, re-save its tensors only:  torch.save({k: v for k, v in torch.load(p, weights_only=False)['state_dict'].items()}, out)")
+        return 2
     for key in ("state_dict", "model", "network"):       # common wrappers
         if isinstance(ck, dict) and key in ck and isinstance(ck[key], dict):
             ck = ck[key]

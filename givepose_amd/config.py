@@ -43,12 +43,14 @@ class PoseNetConfig:
     res_fp32: bool = False
     # build-side switch (fp16 storage only, round 5): the heads' ConvTranspose2d-as-GEMM writes its (B*64, 9*256) column matrix in fp16 (the GEMM's lean
     # epilogue) instead of fp32, and gp_deconv_col2im sums the fp16 summands in fp32: half the bytes of the two launches (75 -> 38 MB per head at
-    # 128 crops); every summand is rounded to fp16 once, like every other activation of the mode.  Measured: DESIGN.md 8.6.
+    # 128 crops); every summand is rounded to fp16 once, like every other activation of the mode.  Measured: +0.3 % end to end (docs/history/round5.md 8.4).
     deconv_cols_f16: bool = True
+    # build-side switch (fp16 storage only, round 5): GroupNorm apply + GELU + the 1x1 out layer of the xyz heads on packed fp16 arithmetic (GP_ACT_PACKED16): the
+    # per-channel scale and shift are rounded to fp16, so the absolute error grows like 2^-11 |group mean| / std (tests/test_hip_ops.py bounds it at ratios 5 .. 50)
+    gnxyz16: bool = True
     # build-side switch (fp16 storage only, round 5): stage 2 (C = 512) runs fc1 -> GELU -> fc2 as ONE launch (convnext_mlp512_kernel) from 128 crops per launch up:
     # the 134 MB hidden tensor never exists (7.2 GB of HBM traffic per 128 crops), but the kernel alone is 8 % slower than the two launches (one wave per SIMD);
-    # end to end: DESIGN.md 8.5.  Off by default.
-    gnxyz16: bool = True                  # fp16 mode: GroupNorm apply + GELU + 1x1 out layer of the xyz heads on packed fp16 arithmetic (GP_ACT_PACKED16)
+    # end to end +0.7 % in flight, -0.8 % serial (docs/history/round5.md 8.5).  Off by default.
     fuse_mlp512: bool = False
 
     @property

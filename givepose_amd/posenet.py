@@ -330,7 +330,9 @@ class PoseNet(nn.Module):
         for r in (16, 32, 64):
             buf[f"ya{r}"], buf[f"yb{r}"] = e(B, r, r, 256), e(B, r, r, 256)
         chunks = max(ops.groupnorm_chunks(B, r * r) for r in (8, 16, 32, 64))
-        buf["gn_partial"], buf["size_scratch"] = f(B * max(chunks, R * R // 64) * 32 * 2), f(B * (cfg.feat_ts + (512 if cfg.main_backbone == "resnet34" else cfg.convnext_dims[-1])))
+        # fused statistics come in 16- / 32- / 64-row chunks (gp_gemm_gn_rows: the library's choice per launch): sized for the finest one at the
+        # largest map, whatever the cost model picks (the small-M kernel would otherwise write past the buffer without any error); _gnarg checks
+        buf["gn_partial"], buf["size_scratch"] = f(B * max(chunks, R * R // 16) * 32 * 2), f(B * (cfg.feat_ts + (512 if cfg.main_backbone == "resnet34" else cfg.convnext_dims[-1])))
         buf["nocs_nchw"], buf["nocs_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["ivfc_nchw"], buf["ivfc_nhwc4"] = f(B, 3, R, R), f(B * R * R, 4)
         buf["mask_out"], buf["size"] = f(B, 1, R, R), f(B, 3)
@@ -382,6 +384,9 @@ class PoseNet(nn.Module):
 
     @staticmethod
     def _gnarg(buf, hw, rows=64):
+        B = buf["mask_out"].shape[0]
+        if B * (hw // rows) * 32 * 2 > buf["gn_partial"].numel():
+            raise RuntimeError(f"fused GroupNorm statistics: {hw // rows} chunks of {rows} rows per image do not fit the plan's gn_partial buffer")
         return (buf["gn_partial"], 32, hw, rows)
 
     def _xyz_head(self, W, head, feat2d, B, buf, out_nchw, out_nhwc4):

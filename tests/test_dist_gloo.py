@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: shard bounds + all-gather of per-crop poses reproduce global crop order."""
+"""CPU, world_size 2 and 8 over gloo: shard bounds + all-gather of per-crop poses reproduce global crop order."""
 import os
 import socket
 
@@ -45,6 +45,23 @@ def test_all_gather_poses_world2(n_items):
     [p.join(60) for p in ps]
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (n_items, 15) for _, _, shape in res)
+
+
+def test_all_gather_poses_world8_configs4_rank_count():
+    """BASELINE configs[4] is 8 ranks x 64 crops: the exact rank count of the driver's scaling run, control flow only (gloo on the CPU -- eight
+    processes on one GPU would exceed the box's process guard, and the builder's boxes have one GPU).  512 crops sharded 8 ways, every rank's
+    gathered poses in global crop order; plus a ragged total (509) through the padded gather."""
+    ctx = mp.get_context("spawn")
+    for n_items in (512, 509):
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_worker, args=(r, 8, port, n_items, q)) for r in range(8)]
+        [p.start() for p in ps]
+        res = [q.get(timeout=240) for _ in ps]
+        [p.join(60) for p in ps]
+        assert sorted(r for r, _, _ in res) == list(range(8))
+        assert all(ok for _, ok, _ in res), res
+        assert all(shape == (n_items, 15) for _, _, shape in res)
 
 
 def test_shard_bounds_cover_and_order():

@@ -806,6 +806,39 @@ def test_groupnorm_apply_xyz(HW):
         assert torch.equal(h2.view(B, HW, 4)[..., :3].permute(0, 2, 1), n2) and float(h2[:, 3].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("ratio", [5.0, 20.0, 50.0])
+def test_groupnorm_apply_xyz_packed16_at_large_group_means(ratio):
+    """GP_ACT_PACKED16 rounds the per-channel scale and SHIFT (b - mean * s) to fp16 before the v_pk_fma, so its absolute error grows like
+    2^-11 * |group mean| / std of the normalised value (round-5 advice: the synthetic weights of the end-to-end tests have group means near
+    zero).  Here the groups' |mean| is `ratio` x their std: the packed form against the fp32-accurate form of the same kernel, bounded by that
+    model (x 256^(1/2) channels x |out-layer weight| through the 1x1 layer) -- and the fp32-accurate form itself against float64."""
+    o = ops()
+    from givepose_amd._lib import ACT_GELU
+    B, C, G, HW = 2, 256, 32, 1024
+    dt = torch.float16
+    x = q(rnd(B, HW, C, seed=161) + ratio, dt)          # std 1 around `ratio`
+    gw, gb = 1 + 0.1 * rnd(C, seed=162), 0.1 * rnd(C, seed=163)
+    ow, ob = rnd(3, C, seed=164, scale=C ** -0.5), rnd(3, seed=165, scale=0.1)
+    xf = x.view(B, HW // 64, 64, G, C // G)
+    mu, sd = xf.mean((2, 4)), xf.std((2, 4))
+    assert float((mu.abs() / sd).min()) > 0.8 * ratio
+    part = torch.stack([xf.sum((2, 4)), (xf * xf).sum((2, 4))], -1).contiguous().view(-1).cuda()
+    y = F.gelu(F.group_norm(x.double().permute(0, 2, 1), G, gw.double(), gb.double(), 1e-5).permute(0, 2, 1))
+    ref = y @ ow.double().t() + ob.double()
+    outs = []
+    for packed in (False, True):
+        nchw, nhwc4 = torch.empty(B, 3, HW, device="cuda"), torch.full((B * HW, 4), 7.0, device="cuda")
+        o.groupnorm_apply_xyz(x.to("cuda", dt), gw.cuda(), gb.cuda(), ow.cuda(), ob.cuda(), nchw, nhwc4, G, ACT_GELU, part, packed16=packed)
+        outs.append(nchw.cpu().double().permute(0, 2, 1))
+    e32, e16 = float((outs[0] - ref).abs().max()), float((outs[1] - ref).abs().max())
+    # fp32-accurate form: the statistics E[x^2] - mean^2 lose (mean / std)^2 of fp32's precision: 2.5e3 x 6e-8 at ratio 50
+    assert e32 < 2e-4 + 3e-7 * ratio * ratio, (ratio, e32)
+    # packed form: per activation ~2^-11 x (1 + ratio) from the rounded shift; 256 of them with random signs through |w| ~ 1/16
+    bound = 4e-3 + 2.0 ** -11 * (1 + ratio) * 1.5
+    print(f"|mean| / std = {ratio}: fp32-accurate form {e32:.2e}, packed fp16 form {e16:.2e} (bound {bound:.2e})")
+    assert e16 < bound, (ratio, e16, bound)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_upsample_and_col2im(dt):
     o = ops()
