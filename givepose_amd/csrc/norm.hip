@@ -751,12 +751,24 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
                  : "memory");
 }
 
-template <int NS, int J, bool NOMFMA = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= 2 x real rows + 7); NOMFMA: timing ablation (wrong results)
-__global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
+// WIDE (maps wider than 16 pixels: ConvNeXt stages 0 / 1): the same kernel on 16 x 8 tiles WITH a column halo -- a stage holds the 14 x 22 pixels around
+// the tile (pixel slot P = r * 22 + cc, the same octet swizzle: 16 consecutive columns of two adjacent rows still hit 16 different bank groups), loaded
+// in pieces of 8 consecutive slots; a lane whose slot lies outside the map is EXEC-masked out of the LDS-DMA instruction and its slot keeps the zero the
+// workgroup wrote once (a piece with no lane inside the map goes to the padding KB instead, so that every slab is the same number of instructions for the
+// counted vmcnt waits).  NS = 2 (C = 128): both slabs resident (two stages); NS = 4: the three-stage ring.
+#define GP_WAIT_VMCNT_J(J) do { if constexpr ((J) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else { static_assert((J) == 9, "J"); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); } } while (0)
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
+__global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
                                                                  const float* __restrict__ bias, const float* __restrict__ lnw,
-                                                                 const float* __restrict__ lnb, half_t* __restrict__ y, int H, float eps) {
-    constexpr int C = 64 * NS, W = 16, TH = 8, NP = TH / 2, IH = TH + 6, PITCH = 18, ROWB = PITCH * 128;
-    constexpr int IN_BYTES = IH * ROWB, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024, NST = 3;   // PAD_OFF: 1 KB, target of the padding DMA instructions
+                                                                 const float* __restrict__ lnb, half_t* __restrict__ y, int H, int Wrt, float eps) {
+    constexpr int C = 64 * NS, TH = 8, NP = TH / 2, IH = TH + 6, PITCH = WIDE ? 22 : 18, ROWB = PITCH * 128;
+    constexpr int IN_BYTES = (IH * ROWB + 1023) / 1024 * 1024, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024;   // PAD_OFF: 1 KB, target of the padding DMA instructions
+    // WIDE: ONE stage and two workgroups per CU (<= 128 registers, 57-59 KB of LDS each): a map of 64 x 64 is many rounds of tiles, so it is another
+    // workgroup's conv that covers this one's prologue, slab latency and epilogue, not a ring inside the workgroup (measured: one workgroup per CU with a
+    // ring ran 131 us at C = 128 against the 16 x 4 kernel's 119: profiles/r06_dw_tall_ab.txt)
+    constexpr int NST = WIDE ? 1 : (NS >= 3 ? 3 : NS);
+    constexpr int NIN_W = (IH * PITCH + 7) / 8;                // WIDE: input pieces of 8 pixel slots per slab (39)
+    const int W = WIDE ? Wrt : 16;
     constexpr int OUT_BYTES = 128 * C * 2;                     // the normalised tile, staged over the dead ring
     constexpr int PAR_OFF = (OUT_BYTES > NST * STAGE ? OUT_BYTES : NST * STAGE), PAR_INS = (3 * C * 4 + 1023) / 1024;
     constexpr int RED_OFF = PAR_OFF + PAR_INS * 1024;          // [2][8 waves][128 px] fp32
@@ -771,12 +783,13 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tpi = H / TH;
+    const int tpr = W / 16, tpi = (H / TH) * tpr;
     const int bid = xcd_chunk(blockIdx.x, gridDim.x);
-    const int b = bid / tpi, h0 = (bid - b * tpi) * TH;
+    const int b = bid / tpi, tin = bid - b * tpi, h0 = (tin / tpr) * TH, w0 = (tin - (tin / tpr) * tpr) * 16;
     const half_t* xb = x + (long)b * H * W * C;
     // halo rows r = 0 .. 13 are image rows h0 - 3 + r; the real ones are rlo .. rhi
     const int rlo = h0 >= 3 ? 0 : 3 - h0, rhi = min(IH - 1, H - 1 - (h0 - 3)), nreal = rhi - rlo + 1;
+    const int nin = WIDE ? NIN_W : 2 * nreal;                  // input pieces (LDS-DMA instructions) per slab
     GP_DWT_MARK(0);
 
     // ---- DMA plan.  ALL LDS-DMA is issued by waves 0-3 (one per SIMD): an LDS-DMA instruction holds its wave for 100-250 cycles (the CU's
@@ -784,15 +797,29 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     //      the hardware favours the older wave of a SIMD, so waves 0-3 finish their MFMAs ~700 cycles before waves 4-7 anyway and used to
     //      spend them at the slab barrier (profiles/r06_dw_tall_stamps.txt).  Instruction slots i = wave + 4 j of a slab: 2 x nreal input
     //      half rows, then 7 KB of taps, then padding.  First thing in the kernel: everything else runs under the first slabs' latency.
-    const bool loader = wave < 4;
-    auto slot_plan = [&](int i, unsigned long long& sb, unsigned& vo, unsigned& ds) {     // i: scalar slot index of a slab's DMA list
-        if (i < 2 * nreal) {
+    constexpr int NLW = WIDE ? 8 : 4;      // loading waves (WIDE: all of them -- another workgroup of the CU multiplies meanwhile, and 6 instead of 12 offset registers keep the wave under 128)
+    const bool loader = wave < NLW;
+    auto slot_plan = [&](int i, unsigned long long& sb, unsigned& vo, unsigned& ds, bool& ok) {     // i: scalar slot index of a slab's DMA list; ok: this lane takes part
+        ok = true;
+        if (WIDE && i < nin) {
+            const int P = i * 8 + (lane >> 3), r = (P * 745) >> 14, cc = P - r * PITCH, o = (lane & 7) ^ ((cc >> 1) & 7);     // P / 22 for P < 312
+            const int gy = h0 - 3 + r, gx = w0 - 3 + cc;
+            ok = r < IH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            sb = (unsigned long long)xb;
+            vo = ok ? (unsigned)(((gy * W + gx) * C + o * 8) * 2) : 0u;
+            ds = (unsigned)(i * 1024);
+            if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(ok) == 0 ? 1 : 0)) {     // nobody inside the map: a padding piece (the instruction count per slab stays fixed)
+                ok = true;
+                vo = (unsigned)((lane & 15) * 16);
+                ds = PAD_OFF;
+            }
+        } else if (!WIDE && i < nin) {
             const int r = rlo + (i >> 1), cc = (i & 1) * 8 + (lane >> 3), o = (lane & 7) ^ ((cc >> 1) & 7);
             sb = (unsigned long long)xb;
             vo = (unsigned)((((h0 - 3 + r) * W + cc) * C + o * 8) * 2);
             ds = (unsigned)((r * PITCH + (i & 1) * 8) * 128);
-        } else if (i < 2 * nreal + 7) {
-            const int t7 = i - 2 * nreal, tap = min(t7 * 8 + (lane >> 3), 48), kh = (tap * 37) >> 8, ch = (lane & 7) ^ kh;   // tap / 7 for tap < 56
+        } else if (i < nin + 7) {
+            const int t7 = i - nin, tap = min(t7 * 8 + (lane >> 3), 48), kh = (tap * 37) >> 8, ch = (lane & 7) ^ kh;   // tap / 7 for tap < 56
             sb = (unsigned long long)wt;
             vo = (unsigned)((tap * C + ch * 8) * 2);
             ds = (unsigned)(TAP_OFF + t7 * 1024);
@@ -810,28 +837,32 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
         glds16_n(f < 3 * C ? (const void*)src : (const void*)gp_zero_page_tu, __builtin_amdgcn_readfirstlane(lds0 + PAR_OFF + wave * 1024));
     }
 #pragma unroll
-    for (int j = 0; j < (J + 1) / 2; ++j) {
+    for (int j = 0; j < (WIDE ? J : (J + 1) / 2); ++j) {
         const int i = wave + 8 * j;
-        if (i < 2 * nreal + 7) {
-            unsigned long long sb; unsigned vo, ds;
-            slot_plan(i, sb, vo, ds);
+        if (i < nin + 7) {
+            unsigned long long sb; unsigned vo, ds; bool ok;
+            slot_plan(i, sb, vo, ds, ok);
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
-            glds16_sv((const void*)(((unsigned long long)hi << 32) | lo), vo, __builtin_amdgcn_readfirstlane(lds0 + ds));
+            const unsigned dd = __builtin_amdgcn_readfirstlane(lds0 + ds);
+            if (ok) glds16_sv((const void*)(((unsigned long long)hi << 32) | lo), vo, dd);
         }
     }
     unsigned voff[J];
+    unsigned vbits = 0;                    // bit j: this lane takes part in piece j (WIDE: lanes whose pixel slot lies outside the map do not)
     unsigned slo[J], shi[J], sdst[J];      // wave-uniform source base of slab 0 (+ 128 bytes per slab: input and taps alike; padding re-reads input row 0) and LDS target
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        unsigned long long sb; unsigned ds;
-        slot_plan((wave & 3) + 4 * j, sb, voff[j], ds);
+        unsigned long long sb; unsigned ds; bool ok;
+        slot_plan((wave & (NLW - 1)) + NLW * j, sb, voff[j], ds, ok);
+        vbits |= ok ? 1u << j : 0u;
         slo[j] = __builtin_amdgcn_readfirstlane((unsigned)sb);
         shi[j] = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
         sdst[j] = __builtin_amdgcn_readfirstlane(lds0 + ds);
     }
     auto issue1 = [&](int s, int j) {      // DMA instruction j of slab s (s, j compile-time at every call site)
         const unsigned long long sbu = (((unsigned long long)shi[j] << 32) | slo[j]) + (unsigned)(s * 128);
-        glds16_sv((const void*)sbu, voff[j], sdst[j] + (s % NST) * STAGE);
+        if constexpr (WIDE) { if ((vbits >> j) & 1) glds16_sv((const void*)sbu, voff[j], sdst[j] + (s % NST) * STAGE); }
+        else glds16_sv((const void*)sbu, voff[j], sdst[j] + (s % NST) * STAGE);
     };
     auto issue = [&](int s) {
 #pragma unroll
@@ -840,7 +871,17 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     GP_DWT_MARK(1);
 
     // ---- zero pixels (two per halo row) and the halo rows outside the map, all stages: written once, never touched by the DMA
-    {
+    if constexpr (WIDE) {
+        // every 16-byte unit of a stage's pixel slots that lies outside the map (edge tiles only; interior tiles write nothing)
+        for (int u = tid; u < NIN_W * 64; u += 512) {
+            const int P = u >> 3, r = (P * 745) >> 14, cc = P - r * PITCH;
+            const int gy = h0 - 3 + r, gx = w0 - 3 + cc;
+            if (!(r < IH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)) {
+#pragma unroll
+                for (int st = 0; st < NST; ++st) *reinterpret_cast<uint4*>(dsm + st * STAGE + u * 16) = uint4{0u, 0u, 0u, 0u};
+            }
+        }
+    } else {
         const int r = tid >> 4, u = tid & 15;
         if (r < IH) {
 #pragma unroll
@@ -860,8 +901,8 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     unsigned sw[7];       // byte offset of this lane's B slot for column shift kw (row block 0): row q, column n + kw - 3
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw) {
-        const int c = n + kw - 3;
-        const int cc = (unsigned)c < 16u ? c : 16 + (c & 1);
+        const int c = WIDE ? n + kw : n + kw - 3;      // WIDE: halo column
+        const int cc = (WIDE || (unsigned)c < 16u) ? c : 16 + (c & 1);
         sw[kw] = (unsigned)(q * ROWB + cc * 128 + (((wave ^ (c >> 1)) & 7) << 4));
     }
     const int kh0 = q - ar, kh1 = q + 4 - ar;
@@ -881,8 +922,10 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
 
     f32x4 acc[NS][NP];
     union Frag { uint4 u; half8 h; };
-    Frag af[2][2], bf[2][6];                       // af[slot][blk]; bf[slot][row block rb / 2]: halo rows rb .. rb + 3, rb = 0, 2, .., 10; slot = (7 s + kw) & 1
-    unsigned wraw[7][2];                           // the 14 taps of this lane's A rows (filter rows kh0 / kh1, all column shifts): read once per slab
+    constexpr bool AF1 = WIDE && NS >= 4;          // (C = 256 at two workgroups per CU: ONE set of A fragments, built in front of its MFMAs: 8 registers)
+    Frag af[AF1 ? 1 : 2][2], bf[2][6];             // af[slot][blk]; bf[slot][row block rb / 2]: halo rows rb .. rb + 3, rb = 0, 2, .., 10; slot = (7 s + kw) & 1
+    constexpr bool PACKW = WIDE && NS >= 4;        // two taps per register (7 instead of 14): C = 256 at two workgroups per CU has 128 registers
+    unsigned wraw[7][PACKW ? 1 : 2];               // the 14 taps of this lane's A rows (filter rows kh0 / kh1, all column shifts): read once per slab
     auto fetch = [&](const char* in_s, int kw, int slot) {
 #pragma unroll
         for (int rb = 0; rb < 6; ++rb) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);
@@ -890,14 +933,16 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     auto taps = [&](const char* in_s) {
 #pragma unroll
         for (int kw = 0; kw < 7; ++kw) {
-            wraw[kw][0] = *reinterpret_cast<const unsigned short*>(in_s + woff0 + kw * 128);
-            wraw[kw][1] = *reinterpret_cast<const unsigned short*>(in_s + woff1 + kw * 128);
+            const unsigned t0 = *reinterpret_cast<const unsigned short*>(in_s + woff0 + kw * 128);
+            const unsigned t1 = *reinterpret_cast<const unsigned short*>(in_s + woff1 + kw * 128);
+            if constexpr (PACKW) wraw[kw][0] = t0 | (t1 << 16);
+            else { wraw[kw][0] = t0; wraw[kw][PACKW ? 0 : 1] = t1; }
         }
     };
     auto build = [&](int kw, int slot) {
-        const unsigned u0 = wraw[kw][0] << sh, u1 = wraw[kw][1] << sh;
-        af[slot][0].u = uint4{u0 & mk0[0], u0 & mk0[1], u0 & mk0[2], u0 & mk0[3]};
-        af[slot][1].u = uint4{u1 & mk1[0], u1 & mk1[1], u1 & mk1[2], u1 & mk1[3]};
+        const unsigned u0 = (PACKW ? wraw[kw][0] & 0xffffu : wraw[kw][0]) << sh, u1 = (PACKW ? wraw[kw][0] >> 16 : wraw[kw][PACKW ? 0 : 1]) << sh;
+        af[AF1 ? 0 : slot][0].u = uint4{u0 & mk0[0], u0 & mk0[1], u0 & mk0[2], u0 & mk0[3]};
+        af[AF1 ? 0 : slot][1].u = uint4{u1 & mk1[0], u1 & mk1[1], u1 & mk1[2], u1 & mk1[3]};
     };
     // ONE barrier per slab, in front of the MFMAs of its LAST column shift: by then every fragment of slab s is in registers (stage s is
     // free: slab s + 3 goes into it) and the loading waves have seen slab s + 1 land (slab s + 2 stays in flight: every slab has two
@@ -905,19 +950,27 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     // so that the matrix pipe does not drain at a slab boundary (a barrier FOLLOWED by the first LDS round trip cost ~700 cycles per slab)
     auto publish = [&](auto sc) {                  // slab s is done being read by this wave; make slab s + 1 visible
         constexpr int s = decltype(sc)::value;
-        if (loader) {
-            if constexpr (s + 2 < NS) {
-                if constexpr (J == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            } else {
+        if constexpr (NST == 1) {                  // one stage: everybody is done reading slab s, THEN slab s + 1 is fetched into the same stage, waited for and published
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (loader) {
+                issue(s + 1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            return;
+        }
+        if (loader) {
+            if constexpr (s + 2 < NS && NST == 3) GP_WAIT_VMCNT_J(J);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of slab s (and, s = -1, the zero fill)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (s + 3 < NS) {
-            if (loader) issue(s + 3);
+        if constexpr (s + NST < NS) {
+            if (loader) issue(s + NST);
         }
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of slab 0 (and of the parameters)
@@ -929,10 +982,10 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     taps(dsm);
     fetch(dsm, 0, 0);
     if (loader) {
-        if (NS > 1) issue(1);
-        if (NS > 2) issue(2);
+        if (NST > 1) issue(1);
+        if (NST > 2) issue(2);
     }
-    build(0, 0);
+    if constexpr (!AF1) build(0, 0);
     static_for<0, NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const char* in_s = dsm + (s % NST) * STAGE;
@@ -945,7 +998,7 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
 #pragma unroll
         for (int kw = 0; kw < 7; ++kw) {           // operands one column shift ahead: the reads and the A-fragment VALU work of shift kw + 1 ride BETWEEN the MFMAs of shift kw
             const int slot = (7 * s + kw) & 1;     //   (an MFMA holds the issue port for 8 of its 16 cycles: in program order behind it, 1-2 other instructions are free)
-            if (kw == 6 && s + 1 < NS) {
+            if (kw == 6 && s + 1 < NS && NST > 1) {
                 GP_DWT_MARK(8 + 4 * s);
                 publish(sc);
                 GP_DWT_MARK(9 + 4 * s);
@@ -954,20 +1007,21 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
                 fetch(nx, 0, slot ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (kw + 1 < 7) { fetch(in_s, kw + 1, slot ^ 1); build(kw + 1, slot ^ 1); }
+            if (kw + 1 < 7) { fetch(in_s, kw + 1, slot ^ 1); if constexpr (!AF1) build(kw + 1, slot ^ 1); }
+            if constexpr (AF1) build(kw, 0);
             if constexpr (!NOMFMA) {
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp)
-                        acc[s][pp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[slot][blk].h, bf[slot][pp + 2 * blk].h, acc[s][pp], 0, 0, 0);
+                        acc[s][pp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[AF1 ? 0 : slot][blk].h, bf[slot][pp + 2 * blk].h, acc[s][pp], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) acc[s][pp][0] += __builtin_bit_cast(float, af[slot][blk].u.x ^ bf[slot][pp + 2 * blk].u.x);   // keeps the operand work alive
+                    for (int pp = 0; pp < NP; ++pp) acc[s][pp][0] += __builtin_bit_cast(float, af[AF1 ? 0 : slot][blk].u.x ^ bf[slot][pp + 2 * blk].u.x);   // keeps the operand work alive
             }
-            if (kw + 1 < 7 && !NOMFMA) {
+            if (kw + 1 < 7 && !NOMFMA && !AF1) {
                 static_for<0, 8>([&](auto ic) {    // MFMA, a fragment read (the first six), one or two VALU instructions
                     constexpr int i = decltype(ic)::value;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -978,7 +1032,12 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (s + 1 < NS) build(0, (7 * (s + 1)) & 1);     // first A fragments of the next slab (its taps were requested behind the barrier)
+        if constexpr (s + 1 < NS && NST == 1) {
+            publish(sc);
+            taps(dsm);
+            fetch(dsm, 0, (7 * (s + 1)) & 1);
+        }
+        if constexpr (s + 1 < NS && !AF1) build(0, (7 * (s + 1)) & 1);     // first A fragments of the next slab (its taps were requested behind the barrier)
         GP_DWT_MARK(7 + 4 * s);
     });
 
@@ -1011,7 +1070,7 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
     }
     char* out_s = dsm;
     constexpr int cpp = C / 8;   // 16-byte chunks per pixel
-    half_t* yb = y + ((long)b * H + h0) * W * C;
+    half_t* yb = y + (((long)b * H + h0) * W + w0) * C;
     // two halves (row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -1041,7 +1100,7 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
         for (int i = tid; i < 64 * cpp; i += 512) {
             const int px = hf * 64 + i / cpp, c = i % cpp;
             const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
-            *reinterpret_cast<uint4*>(yb + (long)px * C + c * 8) = v;
+            *reinterpret_cast<uint4*>(yb + ((long)(px >> 4) * W + (px & 15)) * C + c * 8) = v;
         }
     }
     GP_DWT_MARK(46);
@@ -1051,18 +1110,18 @@ __global__ __launch_bounds__(512, 1) void dwconv7_ln_tall_kernel(const half_t* _
 #endif
 }
 
-template <int NS, int J, bool NOMFMA = false>
-void launch_dw7_tall(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B, int H,
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false>
+void launch_dw7_tall(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B, int H, int W,
                      float eps, hipStream_t s) {
-    constexpr int C = 64 * NS, STAGE = 14 * 18 * 128 + 8 * 1024, OUTB = 128 * C * 2;
-    constexpr int PAR_OFF = (OUTB > 3 * STAGE ? OUTB : 3 * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 128 * 4;
+    constexpr int C = 64 * NS, NST = WIDE ? 1 : (NS >= 3 ? 3 : NS), STAGE = (14 * (WIDE ? 22 : 18) * 128 + 1023) / 1024 * 1024 + 8 * 1024, OUTB = 128 * C * 2;
+    constexpr int PAR_OFF = (OUTB > NST * STAGE ? OUTB : NST * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 128 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, NOMFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, NOMFMA>), dim3(B * (H / 8)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
-                       lnw, lnb, (half_t*)y, H, eps);
+    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA>), dim3(B * (H / 8) * (W / 16)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
+                       lnw, lnb, (half_t*)y, H, W, eps);
 }
 
 // ---------------------------------------------------------------------------- row LayerNorm
@@ -1629,11 +1688,18 @@ static long dw_mfma_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_MFMA_MIN"); return e ? atol(e) : -1l; }();
     return k >= 0 ? k : C == 512 ? 52 : C == 256 ? 33 : 0;
 }
-// fewest half-image workgroups that go to dwconv7_ln_tall_kernel (one workgroup per CU: below ~3/4 of the chip the 16 x 4 tiles fill it better);
+// fewest half-image workgroups that go to dwconv7_ln_tall_kernel on 16-wide maps (one workgroup per CU: at 64 crops = 128 workgroups the 16 x 4 tiles are level,
+// 19.5 against 20.2 us; at 80 / 96 crops it is 33.5 against 21 us: profiles/r06_dw_tall_ab.txt);
 // GP_DW_TALL_MIN=<n>: A/B (a huge value switches the kernel off)
 static long dw_tall_min_wgs() {
-    static const long k = [] { const char* e = getenv("GP_DW_TALL_MIN"); return e ? atol(e) : 192l; }();
+    static const long k = [] { const char* e = getenv("GP_DW_TALL_MIN"); return e ? atol(e) : 130l; }();
     return k;
+}
+// the column-halo form on maps wider than 16 pixels, from this many 16 x 8 tiles up (profiles/r06_dw_tall_ab.txt: C = 128 at 64 x 64 wins from 16 crops,
+// C = 256 at 32 x 32 from 32; GP_DW_TALLW_MIN: one threshold for both, A/B; a huge value switches it off)
+static long dw_tallw_min_wgs(int C) {
+    static const long k = [] { const char* e = getenv("GP_DW_TALLW_MIN"); return e ? atol(e) : -1l; }();
+    return k >= 0 ? k : C == 128 ? 384 : 256;
 }
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
@@ -1661,21 +1727,26 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     gp_timing_label("dwconv%d_ln C%d %dx%d B%d", KS, C, H, W, B);
     const int dbg = act >= 100 ? act - 100 : 0;   // 101 / 102: timing-only ablations (no conv / no DMA), wrong results
     if (act >= 100) act = GP_ACT_NONE;
-    // 16-pixel-wide maps (ConvNeXt stage 2): half-image tiles, from dw_tall_min_wgs() workgroups up (act code 110 forces it, 111: its no-conv ablation)
-    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && W == 16 && H % 8 == 0 && (C == 128 || C == 256 || C == 512) &&
-        x != y && (dbg == 10 || (dbg == 11 && C == 512 && H <= 16) || (dbg == 0 && (long)B * (H / 8) >= dw_tall_min_wgs()))) {
+    // 16 x 8 tiles (dwconv7_ln_tall_kernel): 16-pixel-wide maps (ConvNeXt stage 2) from dw_tall_min_wgs() workgroups up, wider maps (stages 0 / 1: the
+    // column-halo form) from dw_tallw_min_wgs() up; act code 110 forces it, 111 (investigation builds): its no-MFMA ablation
+    const bool tall16 = W == 16 && (C == 128 || C == 256 || C == 512), tallw = W > 16 && W % 16 == 0 && (C == 128 || C == 256);
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && H % 8 == 0 && (tall16 || tallw) && x != y &&
+        (dbg == 10 || (dbg == 11 && C == 512 && H <= 16) || (dbg == 0 && (long)B * (H / 8) * (W / 16) >= (tall16 ? dw_tall_min_wgs() : dw_tallw_min_wgs(C))))) {
 #ifdef GP_DW_STAMPS      // investigation builds only (the instantiation spills): act code 111 = no MFMAs, timing only
-        if (dbg == 11) launch_dw7_tall<8, 8, true>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+        if (dbg == 11) launch_dw7_tall<8, 8, false, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         else
 #endif
-        if (H <= 16) {
-            if (C == 128) launch_dw7_tall<2, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
-            else if (C == 256) launch_dw7_tall<4, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
-            else launch_dw7_tall<8, 8>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+        if (tallw) {
+            if (C == 128) launch_dw7_tall<2, 6, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+            else launch_dw7_tall<4, 6, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+        } else if (H <= 16) {
+            if (C == 128) launch_dw7_tall<2, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+            else if (C == 256) launch_dw7_tall<4, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+            else launch_dw7_tall<8, 8>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         } else {
-            if (C == 128) launch_dw7_tall<2, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
-            else if (C == 256) launch_dw7_tall<4, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
-            else launch_dw7_tall<8, 9>(x, wt, bias, ln_w, ln_b, y, B, H, eps, s);
+            if (C == 128) launch_dw7_tall<2, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+            else if (C == 256) launch_dw7_tall<4, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+            else launch_dw7_tall<8, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         }
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
