@@ -757,11 +757,14 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
 // workgroup wrote once (a piece with no lane inside the map goes to the padding KB instead, so that every slab is the same number of instructions for the
 // counted vmcnt waits).  NS = 2 (C = 128): both slabs resident (two stages); NS = 4: the three-stage ring.
 #define GP_WAIT_VMCNT_J(J) do { if constexpr ((J) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else { static_assert((J) == 9, "J"); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); } } while (0)
-template <int NS, int J, bool WIDE = false, bool NOMFMA = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
+// TH = 4 (16-wide maps only): quarter-image tiles for the launches whose half-image tiles would leave half the chip idle (33 .. 64 crops at stage 2: the
+// strictly serial bs-64 forward): two row pairs per wave -- the B-fragment sharing is gone (4 fragments for 4 MFMAs per column shift) -- everything else as above.
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
 __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
                                                                  const float* __restrict__ bias, const float* __restrict__ lnw,
                                                                  const float* __restrict__ lnb, half_t* __restrict__ y, int H, int Wrt, float eps) {
-    constexpr int C = 64 * NS, TH = 8, NP = TH / 2, IH = TH + 6, PITCH = WIDE ? 22 : 18, ROWB = PITCH * 128;
+    constexpr int C = 64 * NS, NP = TH / 2, IH = TH + 6, PITCH = WIDE ? 22 : 18, ROWB = PITCH * 128, NPX = 16 * TH, NBF = NP + 2;
+    static_assert(TH == 8 || (TH == 4 && !WIDE), "tile height");
     constexpr int IN_BYTES = (IH * ROWB + 1023) / 1024 * 1024, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024;   // PAD_OFF: 1 KB, target of the padding DMA instructions
     // WIDE: ONE stage and two workgroups per CU (<= 128 registers, 57-59 KB of LDS each): a map of 64 x 64 is many rounds of tiles, so it is another
     // workgroup's conv that covers this one's prologue, slab latency and epilogue, not a ring inside the workgroup (measured: one workgroup per CU with a
@@ -769,17 +772,17 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     constexpr int NST = WIDE ? 1 : (NS >= 3 ? 3 : NS);
     constexpr int NIN_W = (IH * PITCH + 7) / 8;                // WIDE: input pieces of 8 pixel slots per slab (39)
     const int W = WIDE ? Wrt : 16;
-    constexpr int OUT_BYTES = 128 * C * 2;                     // the normalised tile, staged over the dead ring
+    constexpr int OUT_BYTES = NPX * C * 2;                     // the normalised tile, staged over the dead ring
     constexpr int PAR_OFF = (OUT_BYTES > NST * STAGE ? OUT_BYTES : NST * STAGE), PAR_INS = (3 * C * 4 + 1023) / 1024;
     constexpr int RED_OFF = PAR_OFF + PAR_INS * 1024;          // [2][8 waves][128 px] fp32
-    static_assert(RED_OFF + 2 * 8 * 128 * 4 <= 160 * 1024, "LDS");
+    static_assert(RED_OFF + 2 * 8 * NPX * 4 <= 160 * 1024, "LDS");
     static_assert(PAR_INS <= 8, "one parameter DMA instruction per wave");
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
     const float* par_s = reinterpret_cast<const float*>(dsm + PAR_OFF);
     float* red_s = reinterpret_cast<float*>(dsm + RED_OFF);
-    float* red2_s = red_s + 8 * 128;
+    float* red2_s = red_s + 8 * NPX;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -923,12 +926,12 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     f32x4 acc[NS][NP];
     union Frag { uint4 u; half8 h; };
     constexpr bool AF1 = WIDE && NS >= 4;          // (C = 256 at two workgroups per CU: ONE set of A fragments, built in front of its MFMAs: 8 registers)
-    Frag af[AF1 ? 1 : 2][2], bf[2][6];             // af[slot][blk]; bf[slot][row block rb / 2]: halo rows rb .. rb + 3, rb = 0, 2, .., 10; slot = (7 s + kw) & 1
+    Frag af[AF1 ? 1 : 2][2], bf[2][NBF];           // af[slot][blk]; bf[slot][row block rb / 2]: halo rows rb .. rb + 3, rb = 0, 2, .., 2 (NP + 1); slot = (7 s + kw) & 1
     constexpr bool PACKW = WIDE && NS >= 4;        // two taps per register (7 instead of 14): C = 256 at two workgroups per CU has 128 registers
     unsigned wraw[7][PACKW ? 1 : 2];               // the 14 taps of this lane's A rows (filter rows kh0 / kh1, all column shifts): read once per slab
     auto fetch = [&](const char* in_s, int kw, int slot) {
 #pragma unroll
-        for (int rb = 0; rb < 6; ++rb) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);
+        for (int rb = 0; rb < NBF; ++rb) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);
     };
     auto taps = [&](const char* in_s) {
 #pragma unroll
@@ -1022,12 +1025,12 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
                     for (int pp = 0; pp < NP; ++pp) acc[s][pp][0] += __builtin_bit_cast(float, af[AF1 ? 0 : slot][blk].u.x ^ bf[slot][pp + 2 * blk].u.x);   // keeps the operand work alive
             }
             if (kw + 1 < 7 && !NOMFMA && !AF1) {
-                static_for<0, 8>([&](auto ic) {    // MFMA, a fragment read (the first six), one or two VALU instructions
+                static_for<0, 2 * NP>([&](auto ic) {    // MFMA, a fragment read (the first NP + 2), VALU instructions (10 per column shift)
                     constexpr int i = decltype(ic)::value;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if constexpr (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if constexpr (i < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    if constexpr (i < NBF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if constexpr (NP == 4) { if constexpr (i < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+                    else { if constexpr (i < 2) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
             for (int e = 0; e < 4; ++e) { a += acc[s][pp][e]; a2 = fmaf(acc[s][pp][e], acc[s][pp][e], a2); }
         a += __shfl_xor(a, 16);
         a2 += __shfl_xor(a2, 16);
-        if ((q & 1) == 0) { const int px = (2 * pp + rsel) * 16 + n; red_s[wave * 128 + px] = a; red2_s[wave * 128 + px] = a2; }
+        if ((q & 1) == 0) { const int px = (2 * pp + rsel) * 16 + n; red_s[wave * NPX + px] = a; red2_s[wave * NPX + px] = a2; }
     }
     GP_DWT_MARK(40);
     __syncthreads();      // also: every wave is done with the last slab's stage, which the output tile overlays
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
         const int px = (2 * pp + rsel) * 16 + n;
         float a = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) { a += red_s[w8 * 128 + px]; a2 += red2_s[w8 * 128 + px]; }
+        for (int w8 = 0; w8 < 8; ++w8) { a += red_s[w8 * NPX + px]; a2 += red2_s[w8 * NPX + px]; }
         const float mean = a * invC;
         rstd[pp] = rsqrtf(fmaxf(a2 * invC - mean * mean, 0.f) + eps);
         nmr[pp] = -mean * rstd[pp];
@@ -1071,7 +1074,7 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     char* out_s = dsm;
     constexpr int cpp = C / 8;   // 16-byte chunks per pixel
     half_t* yb = y + (((long)b * H + h0) * W + w0) * C;
-    // two halves (row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
+    // two halves (TH = 8: row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -1080,8 +1083,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
             const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 64 + cq);
             const int chunk = s * 8 + wave;
 #pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                const int pp = hf * 2 + p2;
+            for (int p2 = 0; p2 < NP / 2; ++p2) {
+                const int pp = hf * (NP / 2) + p2;
                 half4 ov;
                 ov[0] = (_Float16)fmaf(fmaf(acc[s][pp][0], rstd[pp], nmr[pp]), gw.x, gb.x);
                 ov[1] = (_Float16)fmaf(fmaf(acc[s][pp][1], rstd[pp], nmr[pp]), gw.y, gb.y);
@@ -1097,8 +1100,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
         asm volatile("" ::: "memory");
         GP_DWT_MARK(43 + 2 * hf);
 #pragma unroll 4
-        for (int i = tid; i < 64 * cpp; i += 512) {
-            const int px = hf * 64 + i / cpp, c = i % cpp;
+        for (int i = tid; i < (NPX / 2) * cpp; i += 512) {
+            const int px = hf * (NPX / 2) + i / cpp, c = i % cpp;
             const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
             *reinterpret_cast<uint4*>(yb + ((long)(px >> 4) * W + (px & 15)) * C + c * 8) = v;
         }
@@ -1110,17 +1113,17 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
 #endif
 }
 
-template <int NS, int J, bool WIDE = false, bool NOMFMA = false>
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8>
 void launch_dw7_tall(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B, int H, int W,
                      float eps, hipStream_t s) {
-    constexpr int C = 64 * NS, NST = WIDE ? 1 : (NS >= 3 ? 3 : NS), STAGE = (14 * (WIDE ? 22 : 18) * 128 + 1023) / 1024 * 1024 + 8 * 1024, OUTB = 128 * C * 2;
-    constexpr int PAR_OFF = (OUTB > NST * STAGE ? OUTB : NST * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 128 * 4;
+    constexpr int C = 64 * NS, NST = WIDE ? 1 : (NS >= 3 ? 3 : NS), STAGE = ((TH + 6) * (WIDE ? 22 : 18) * 128 + 1023) / 1024 * 1024 + 8 * 1024, OUTB = 16 * TH * C * 2;
+    constexpr int PAR_OFF = (OUTB > NST * STAGE ? OUTB : NST * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 16 * TH * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA>), dim3(B * (H / 8) * (W / 16)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
+    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH>), dim3(B * (H / TH) * (W / 16)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
                        lnw, lnb, (half_t*)y, H, W, eps);
 }
 
@@ -1701,6 +1704,10 @@ static long dw_tallw_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_TALLW_MIN"); return e ? atol(e) : -1l; }();
     return k >= 0 ? k : C == 128 ? 384 : 256;
 }
+static bool dw_tall4_enabled() {     // GP_DW_TALL4=0: A/B switch for the quarter-image form
+    static const bool on = [] { const char* e = getenv("GP_DW_TALL4"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static bool dw_single_buffer() {   // A/B: the single-buffered (two workgroups per CU) C = 512 variant for any grid
     static const bool on = [] { const char* e = getenv("GP_DW_NBUF1"); return e && e[0] == '1'; }();
     return on;
@@ -1748,6 +1755,14 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
             else if (C == 256) launch_dw7_tall<4, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
             else launch_dw7_tall<8, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         }
+        GP_LAUNCH_CHECK("gp_dwconv_ln");
+    }
+    // quarter-image tiles (TH = 4) of 16-wide maps where the half-image tiles would leave the chip half empty (33 .. 64 crops at stage 2); act code 112 forces it
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && H % 4 == 0 && tall16 && x != y &&
+        (dbg == 12 || (dbg == 0 && (long)B * (H / 4) >= 52 && (long)B * (H / 8) < dw_tall_min_wgs() && dw_tall4_enabled()))) {      // (from 13 crops: where the 16 x 4 MFMA kernel took over from the strip kernel; 16 crops: 12.5 against 16.4 us)
+        if (C == 128) launch_dw7_tall<2, 8, false, false, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+        else if (C == 256) launch_dw7_tall<4, 8, false, false, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+        else launch_dw7_tall<8, 8, false, false, 4>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && (dbg == 0 || dbg >= 5) && dbg < 10 && H % 4 == 0 && W % 16 == 0 &&

@@ -10,12 +10,12 @@ assert int(os.environ.get("GP_DW_TALL_MIN", "0")) > 10 ** 6 and int(os.environ.g
 g = torch.Generator().manual_seed(3)
 SHAPES = ((512, 16, 16, 128), (512, 16, 16, 64), (512, 16, 16, 256), (128, 64, 64, 128), (128, 64, 64, 64), (256, 32, 32, 128), (256, 32, 32, 64))
 if os.environ.get('SMALL') == '1':
-    SHAPES = ((128, 64, 64, 32), (128, 64, 64, 16), (128, 64, 64, 8), (128, 64, 64, 4), (256, 32, 32, 32), (256, 32, 32, 16), (256, 32, 32, 8), (512, 16, 16, 96), (512, 16, 16, 80))
+    SHAPES = ((512, 16, 16, 64), (512, 16, 16, 48), (512, 16, 16, 32), (512, 16, 16, 24), (512, 16, 16, 16), (512, 16, 16, 96), (512, 16, 16, 80), (256, 32, 32, 32), (128, 64, 64, 8))
 for (C, H, Wd, B) in SHAPES:
     x = torch.randn(B, H, Wd, C, generator=g).half().cuda()
     w = (torch.randn(49, C, generator=g) / 7).half().cuda()
     b, lw, lb = (torch.randn(C, generator=g).cuda() for _ in range(3))
-    ys = {a: torch.empty_like(x) for a in (0, 110)}
+    ys = {a: torch.empty_like(x) for a in ((0, 110, 112) if Wd == 16 else (0, 110))}
     def timed(a, n=40):
         f = lambda: ops.dwconv_ln(x, w, b, lw, lb, ys[a], 7, act=a)
         for _ in range(3): f()
@@ -31,4 +31,4 @@ for (C, H, Wd, B) in SHAPES:
     d = float((ys[0].float() - ys[110].float()).abs().max())
     mb = 2 * x.numel() * 2 / 1e6
     print(f"C={C} {H}x{Wd} B={B} ({mb:.0f} MB in + out: {mb / 6.3:.1f} us at 6.3 TB/s): 16x4 kernel {statistics.median(t[0]):.1f} us | tall {statistics.median(t[110]):.1f} us "
-          f"| max |tall - old| {d:.2e}", flush=True)
+          + (f"| quarter-image tiles {statistics.median(t[112]):.1f} us " if 112 in t else "") + f"| max |tall - old| {d:.2e}", flush=True)

@@ -693,6 +693,10 @@ def test_dwconv_ln_tall_tiles(C, H, B, offset, W):
     out2 = torch.zeros_like(out)      # bitwise repeatable
     o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2, 7, act=110)
     assert torch.equal(out, out2)
+    if W == 16:                       # the quarter-image form (TH = 4; act code 112): what a launch of 33 .. 64 crops at stage 2 takes
+        out4 = torch.zeros_like(out)
+        o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out4, 7, act=112)
+        assert rel_err(out4, ref) < (2 * TOL[dt] if offset else TOL[dt]), rel_err(out4, ref)
 
 
 @pytest.mark.parametrize("dt", DT)
