@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(512) void gemm_wreg2_kernel(const GemmKP p) {
 
 // =====================================================================================================
 // Weights-in-registers GEMM, third form (variant 19, round 5): gemm_wreg2_kernel on v_mfma_f32_32x32x16_f16.
-// Why: the kernel is bound by the SIMD's vector ISSUE, not by its matrix pipe (header of gemm_wreg_kernel): an MFMA
+// Why: the kernel is bound by the SIMD's vector ISSUE, not by its matrix pipe (header of gemm_wreg_kernel; docs/history/round4.md 9.1): an MFMA
 // holds the issue port for 8 cycles whatever its shape, and a 32x32x16 MFMA does in 32 pipe cycles what two 16x16x32 MFMAs do in
 // 2 x 16 -- half the MFMA issue slots per FLOP (per tile and wave 32 x 8 = 256 cycles instead of 64 x 8 = 512), the same fragment
 // reads (one ds_read_b128 per K step of 16 instead of two per K step of 32) and the same registers (a wave's 32 W rows x 512 K are

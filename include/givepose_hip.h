@@ -137,7 +137,7 @@ typedef struct gp_gemm_desc {
                   * conv (Cout 256), 16 / 17 = K 512 with the weight slice resident in registers (17: 16-byte stores, needs ldc % 8 == 0 and a
                   * 16-byte aligned C; the default of stage-2 fc1 until round 4), 19 / 20 / 21 / 22 = 17's arithmetic with two accumulator sets (round 5): 19 / 20 on
                   * 32x32x16 MFMAs, 22 / 21 on 16x16x32; 20 / 21 apply GP_EPI_GELU on packed fp16 (13 v_pk_* operations per value pair, absolute error of
-                  * one fp16 rounding: DESIGN.md 8.2; refused for the other epilogues); 21 = the default of stage-2 fc1 (22 with GP_GELU16=0),
+                  * one fp16 rounding: docs/history/round5.md 8.2; refused for the other epilogues); 21 = the default of stage-2 fc1 (22 with GP_GELU16=0),
                   * 18 = the small-M latency kernel (few rows -- the detections of one
                   * frame: fp16 in / out, N % 32 == 0, M % 16 == 0 (% 64 with gn_partial), plain GEMM or conv; chosen by variant 0 when its
                   * estimate beats the tile kernels'; a split-K request is ignored; 218 / 318 / 418 force the 16 / 32 / 64-row tile),

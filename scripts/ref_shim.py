@@ -469,6 +469,16 @@ def install():
         return FLAGS
     _installed = True
     sys.dont_write_bytecode = True
+    # GP_SHIM_REAL=timm,torchvision,cv2: use the INSTALLED package instead of this file's stand-in for the names listed (re-verifying
+    # rows a2 / a13 / f2 / f1 where the packages exist).  Default: every name of _STUB_TOPLEVEL is stubbed, installed or not (the committed vectors were made that way).
+    import importlib.util
+    import os
+    for name in filter(None, os.environ.get("GP_SHIM_REAL", "").split(",")):
+        if name in _STUB_TOPLEVEL and importlib.util.find_spec(name) is not None:
+            _STUB_TOPLEVEL.discard(name)
+            print(f"[ref_shim] using the installed {name}", file=sys.stderr)
+        else:
+            print(f"[ref_shim] GP_SHIM_REAL: {name} is not installed (or not a stubbed name): keeping the stand-in", file=sys.stderr)
     # transformers probes for torchvision at import time: load it before the stubs exist
     from transformers import ConvNextConfig, ConvNextModel  # noqa: F401
     sys.meta_path.insert(0, _StubFinder())
