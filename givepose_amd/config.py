@@ -29,9 +29,10 @@ class PoseNetConfig:
     # build-side switch (not a reference flag): fp16 stages with C in {128, 256} run fc1 -> GELU -> fc2 as one kernel
     fuse_mlp: bool = True
     # ... from this many crops per forward up: below it the fused kernel's few workgroups each walk both weight matrices and
-    # the two plain GEMMs are the shorter chain (scripts/latency_ab.py on MI355X: B = 1 3.06 -> 2.94 ms, B = 4 3.40 -> 3.12,
-    # B = 16 3.80 -> 3.68)
-    fuse_mlp_min_batch: int = 32
+    # the two plain GEMMs are the shorter chain.  Round 6 (scripts/fuse_mlp_sweep.py, profiles/r06_fuse_mlp_sweep.txt, with the round-5 four-wave
+    # form of the C = 128 kernel): forward at B = 4 / 8 / 12: 2.30 / 2.81 / 3.17 ms fused against 2.24 / 2.76 / 3.16 as two GEMMs; B = 16 / 24 / 32 / 48:
+    # 3.20 / 3.89 / 4.13 / 5.17 against 3.31 / 4.00 / 4.33 / 5.48 -> 16 (rounds 2-5: 32, fitted on the eight-wave kernel)
+    fuse_mlp_min_batch: int = 16
     # build-side switch: fp16 stage with C = 512 runs the depth-wise conv one workgroup per 128-channel slab and applies
     # the block's LayerNorm in fc1's GEMM epilogue (algebraically identical: LN is affine per row).  Measured on MI355X
     # (bs 64): depth-wise 25.2 -> 22.9 us but fc1 52 -> 58 us per block, a net loss, hence off by default.

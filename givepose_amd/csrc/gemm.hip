@@ -2223,6 +2223,10 @@ static bool wreg_enabled() {
     static const bool on = [] { const char* e = getenv("GP_GEMM_WREG"); return !(e && e[0] == '0'); }();
     return on;
 }
+static long wreg_min_rows() {
+    static const long k = [] { const char* e = getenv("GP_GEMM_WREG_MIN_ROWS"); return e ? atol(e) : 6144l; }();
+    return k;
+}
 
 static int wreg_variant() {   // GP_GEMM_WREG_VARIANT=17|19|20|21|22: which weights-in-registers kernel the automatic choice takes (A/B switch; default 21,
                               // and 22 -- the same kernel with the activation in fp32 -- for the epilogues other than GELU)
@@ -2440,14 +2444,15 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
             // co_scheduled (several batches in flight: PoseNet(inflight > 1)): a launch need not fill the chip by itself,
             // the 256x256 ping-pong tile is then the cheapest per FLOP even for 32-128 tiles (GP_GEMM_PP_MIN_TILES: A/B)
             const bool fills = tA >= 192 || d->epilogue == GP_EPI_LNFOLD_GELU;
-            // K = 512, >= 12288 rows, >= 1024 columns (stage-2 fc1 at bs 64): weights in registers (48.5 us against 51.4 for
-            // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py); shorter M does not amortise the
-            // 256 KB weight prologue per CU.  GP_GEMM_WREG=0: A/B switch
+            // K = 512, >= 6144 rows, >= 1024 columns (stage-2 fc1 from 24 crops up): weights in registers (bs 64: 48.5 us against 51.4 for
+            // the ping-pong tile and 59-61 for the 256x128 tile, scripts/wreg_bench.py; round 6, scripts/midsize_variants.py: 24 crops 22.8 against 25.4 us
+            // for the 256x128 tile, 32 crops 26.8 against 28.9; at 16 crops the 128x128 tile wins, 16.6 against 19.0: shorter M does not amortise the
+            // 256 KB weight prologue per CU).  GP_GEMM_WREG=0 / GP_GEMM_WREG_MIN_ROWS=<n>: A/B switches
             // (split-operand mode: the K loop is three times as long, which is what the ping-pong tile's fill / drain is weighed
             // against; measured, scripts/split_variants.py: it wins from ~140 tiles of 256 x 256 up, below that the 128 x 128
             // two-workgroups-per-CU tile does; the 256 x 128 tile never)
             if (split) variant = (d->N % 256 == 0 && tA >= 140 && pp_enabled()) ? 10 : 7;
-            else if (wreg_ok && d->M >= 12288 && d->N >= 1024 && wreg_enabled()) variant = (d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0) ? (wreg_variant() == 20 && d->epilogue != GP_EPI_GELU ? 19 : wreg_variant() == 21 && d->epilogue != GP_EPI_GELU ? 22 : wreg_variant()) : 16;
+            else if (wreg_ok && d->M >= wreg_min_rows() && d->N >= 1024 && wreg_enabled()) variant = (d->ldc % 8 == 0 && ((size_t)d->C & 15) == 0) ? (wreg_variant() == 20 && d->epilogue != GP_EPI_GELU ? 19 : wreg_variant() == 21 && d->epilogue != GP_EPI_GELU ? 22 : wreg_variant()) : 16;
             else if (d->N % 256 == 0 && d->K >= (d->co_scheduled ? pp_min_k() : 2 * pp_min_k()) && pp_enabled() && (fills || (d->co_scheduled && tA >= co_min_tiles()) || tA >= pp_min_tiles())) variant = 10;
             else variant = (d->N % 256 == 0 && fills) ? 8 : 7;
         }

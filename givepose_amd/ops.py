@@ -147,6 +147,10 @@ def auto_splitk(M, N, K, esz, n_cu=256):
     split saves (feat_reducer 14.6 -> 22.7 us, fc2 16.7 -> 16.3 us)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nkt = K // (128 // esz)
+    # round 6 (scripts/stage3_splitk.py, profiles/r06_stage3_splitk.txt): ConvNeXt stage-3 fc2 (N = 1024, K = 4096) at 16 .. 32 crops is 64 .. 128 tiles of 128 x 128
+    # with a 64-step K loop on a quarter to a half of the chip: four K ranges + the reduce kernel 43.6 -> 28.1 / 43.9 -> 31.4 / 43.9 -> 33.9 us (from 192 tiles: nothing)
+    if esz == 2 and K >= 4096 and 32 < tiles <= 128:
+        return 4
     if tiles >= 32 or nkt < 32:
         return 1
     return max(1, min(nkt // 4, (n_cu + tiles - 1) // tiles, 32))

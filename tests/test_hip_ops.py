@@ -70,6 +70,25 @@ def test_gemm_splitk_and_epilogues(dt, splitk):
         assert rel_err(out, ref) < TOL[dt], epi
 
 
+def test_gemm_auto_splitk_stage3_fc2_shape():
+    """Round 6: the automatic split-K of long-K GEMMs on 33 .. 128 tiles (ConvNeXt stage-3 fc2 at 16 .. 32 crops): gamma-scaled residual epilogue IN PLACE
+    (residual = out, as PoseNet calls it), the route the default takes, against fp32 and against the unsplit launch."""
+    o = ops()
+    dt = torch.float16
+    M, N, K = 1536, 1024, 4096
+    assert o.auto_splitk(M, N, K, 2) == 4 and o.auto_splitk(3072, N, K, 2) == 1 and o.auto_splitk(M, N, 2048, 2) == 1 and o.auto_splitk(M, N, K, 4) == 1
+    x, w, b = q(rnd(M, K, seed=14), dt), q(rnd(N, K, seed=15, scale=K ** -0.5), dt), rnd(N, seed=16)
+    res, gamma = q(rnd(M, N, seed=17), dt), rnd(N, seed=18)
+    ref = res + gamma * (x @ w.t() + b)
+    outs = []
+    for sk in (None, 1):
+        out = res.to("cuda", dt).clone()
+        o.gemm(x.to("cuda", dt), w.to("cuda", dt), out, bias=b.cuda(), epilogue=o.EPI_SCALE_RES, gamma=gamma.cuda(), residual=out, splitk=sk)
+        assert rel_err(out, ref) < TOL[dt], sk
+        outs.append(out)
+    assert float((outs[0].float() - outs[1].float()).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_gemm_strided_views(dt):
     """ldx (column slice of a wider matrix) and ldc (write into a concat buffer)."""

@@ -398,7 +398,8 @@ def test_bs64_default_wiring_runs_the_tuned_kernels(net16):
     (4, {"gemm v7 M1024 N2048 K512 epi1": 27, "gemm v18 M1024 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v18 32x32": 4, "conv3x3 s1 v18 16x16": 4,
          "conv3x3 s1 v18 16x16 Cin256 Cout256 M1024 +gn32": 4, "gemm v23 M4 N2048 K8192 epi3": 1, "gemm v23 M4 N256 K1024 epi3": 2}),
     (8, {"gemm v7 M2048 N2048 K512 epi1": 27, "gemm v18 M2048 N512 K2048 epi4": 27, "conv3x3 s1 v7 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4}),
-    (16, {"gemm v7 M4096 N2048 K512 epi1": 27, "gemm v7 M4096 N512 K2048 epi4": 27, "conv3x3 s1 v13 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4})])
+    (16, {"gemm v7 M4096 N2048 K512 epi1": 27, "gemm v7 M4096 N512 K2048 epi4": 27, "conv3x3 s1 v13 64x64": 4, "conv3x3 s1 v7 32x32": 4, "conv3x3 s1 v18 16x16": 4,
+          "convnext_mlp C128": 3, "convnext_mlp C256": 3})])       # (round 6: the fused MLP of stages 0 / 1 from 16 crops, the weights-in-registers fc1 from 24)
 def test_small_batch_wiring_is_pinned(net16, B, pins):
     """Dispatch guard for the batches between the latency path and the bench shape (round-4 advice): the automatic choice between the latency
     kernel (variant 18, cost model fitted on 1-8 crops, capped at 16 384 rows) and the tile kernels moves a whole forward by tens of percent
