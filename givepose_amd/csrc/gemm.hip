@@ -33,6 +33,7 @@ struct GemmKP {
     int tiles_m, tiles_n, nkt, kt_per_split, splitk;
     float* gn_partial;  // fused GroupNorm statistics (large-tile kernels): (B, HW/64, G, 2) chunk sums, or null
     int gn_cpg, gn_hw;
+    int early;               // gemm_wreg3_kernel: start the first tile while the weight slice streams in (round 6)
     const float* ln_stats;   // GP_EPI_LNFOLD_GELU: (M, 2, ln_nsl) partial row moments, ln_s (N) column sums of W
     const float* ln_s;
     int ln_nsl;
@@ -1813,22 +1814,33 @@ __global__ __launch_bounds__(512) void gemm_wreg3_kernel(const GemmKP p) {
         for (int r = 0; r < 16; ++r) b16[r] = p.bias ? p.bias[nb + 16 * (r >> 3) + 8 * h + (r & 7)] : 0.0f;
     } else {
         // lane (fr, fq) of fragment (nt, ks) holds W[nb + 8 (fr / 4) + 4 nt + fr % 4][ks * 32 + fq * 8 .. + 8]
+        // (the bias FIRST: it is the C operand of tile 0's first MFMAs, and vmcnt retires in order -- behind the weights it would make them wait for the whole slice)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b16[r] = (p.bias && r < 8) ? p.bias[nb + fq * 8 + r] : 0.0f;   // registers 4 nt .. + 4: channels nb + 8 fq + 4 nt .. + 4
+        asm volatile("" ::: "memory");
         const half_t* Wp = reinterpret_cast<const half_t*>(p.W) + (long)(nb + (fr >> 2) * 8 + (fr & 3)) * K + fq * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) wf[nt * KS + ks] = *reinterpret_cast<const uint4*>(Wp + (long)nt * 4 * K + ks * 32);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) b16[r] = (p.bias && r < 8) ? p.bias[nb + fq * 8 + r] : 0.0f;   // registers 4 nt .. + 4: channels nb + 8 fq + 4 nt .. + 4
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc does not wait for the W loads inside the loop
-    prefetch_retire(pfs);
+    // Round 6 (p.early): the first tile does NOT wait for the whole 256 KB weight slice.  The wave's eight X pieces of tiles 0 / 1 are its OLDEST vector-memory
+    // operations (asm volatile with a memory clobber: nothing tracked moves in front of them) and the 32 weight fragments are ordinary loads hipcc tracks, issued in the
+    // order tile 0 consumes them: vmcnt(32) says the pieces have landed whatever else is in flight, and hipcc's own waits in front of each fragment's first MFMA let tile 0
+    // start on fragment 0 while fragments 1 .. 31 stream in.  (LDS-DMA instructions hipcc cannot see only make its counted waits stricter: extra YOUNGER operations.)
+    // After tile 0 every fragment has been waited for, so no wait reaches the loop.  GP_GEMM_WREG_EARLY=0: the old full wait (A/B).
+    if (p.early) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the builtin, so that hipcc does not wait for the W loads inside the loop
+        prefetch_retire(pfs);
+    }
     __builtin_amdgcn_s_barrier();         // tiles 0 and 1 are published
 
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     clk_stamp(p, 0);
     tile(0, P0{}, std::false_type{});
+    if (p.early) prefetch_retire(pfs);
     sync(0);
     int t = 1;
     for (; t + 1 < T; t += 2) {
@@ -2223,6 +2235,10 @@ static bool wreg_enabled() {
     static const bool on = [] { const char* e = getenv("GP_GEMM_WREG"); return !(e && e[0] == '0'); }();
     return on;
 }
+static bool wreg_early() {
+    static const bool on = [] { const char* e = getenv("GP_GEMM_WREG_EARLY"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static long wreg_min_rows() {
     static const long k = [] { const char* e = getenv("GP_GEMM_WREG_MIN_ROWS"); return e ? atol(e) : 6144l; }();
     return k;
@@ -2388,6 +2404,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
     int variant = d->variant % 100;
     p.dbg = d->variant / 100;
+    p.early = wreg_early() ? 1 : 0;
     // Workgroup tile of the latency kernel: (16 MT) x 32, MT in {1, 2, 4}, by a cost model fitted to scripts/small_m_variants.py
     // (profiles/r04_small_m_tiles.txt; hipGraph chains, 1-8 crops, K 512-4096): ~2.6 us of launch + epilogue; ONE workgroup moves
     // its (16 MT + 32) rows of K halfs in ~1 us + KB / 60; a CU that holds several workgroups sustains ~45 KB/us; the 64-row
