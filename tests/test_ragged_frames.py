@@ -131,3 +131,21 @@ def test_plan_cache_is_bounded():
                 assert torch.equal(first, r)       # rebuilt after eviction: same result
         assert len(net._plans) <= 3
     assert [k[0] for k in net._plans] == [4, 5, 1]
+
+
+def test_groups_argument_checks_and_uncoupled_configs():
+    """groups must be positive sizes summing to the crop count; where nothing couples the crops of a forward (use_dcn = '' / the attention encoder) a grouped
+    forward IS the plain forward: same plan, same bits."""
+    from givepose_amd import PoseNet, PoseNetConfig
+    data = _batch(6, 77)
+    net = PoseNet(PoseNetConfig(), seed=0, dtype=torch.float16).cuda()
+    for bad in ([], [3, 2], [6, 0], [7, -1], [2, 2, 3]):
+        with pytest.raises(ValueError):
+            net.forward_device(data, groups=bad)
+    for kw in (dict(use_dcn=""), dict(nocsmap_encoder="att")):
+        n2 = PoseNet(PoseNetConfig(**kw), seed=0, dtype=torch.float16).cuda()
+        a = n2.forward_device(data, groups=[1, 2, 3])["rot"].clone()
+        b = n2.forward_device(data)["rot"].clone()
+        assert torch.equal(a, b) and all(not k[2] for k in n2._plans), kw
+    # a ragged total beyond the largest bucket pads to a multiple of 64
+    assert PoseNet.ragged_bucket(129) == 192 and PoseNet.ragged_bucket(8) == 8 and PoseNet.ragged_bucket(9) == 16
