@@ -1,5 +1,7 @@
+"""Round 6: stage-2 fc1 (gemm_wreg3_kernel, variant 21) alone at 24 / 64 / 128 crops: run once with GP_GEMM_WREG_EARLY=0 (full weight wait) and once without
+(the first tile starts while the weight slice streams in), alternating processes: profiles/r06_fc1_early_ab.txt."""
 import os, sys, statistics
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from givepose_amd import ops
 for M in (6144, 16384, 32768):
