@@ -294,6 +294,189 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? GP_MLP_WGS : 1) void convnext_
 }
 
 // =====================================================================================================
+// The same block on v_mfma_f32_32x32x16_f16 (round 6; review item 4 of round 5): an MFMA of this shape holds the SIMD's issue port for 8 of its 32 cycles instead of 8 of 16,
+// i.e. per FLOP half the MFMA issue slots, which leaves the GELU's VALU work (13 packed operations per value pair: 4 x the GELU work per FLOP of stage-2 fc1)
+// 5-6 issue slots behind every MFMA instead of 1-2 (profiles/r05_mfma_valu_coissue.txt) -- at ~10 % of clock (profiles/r05_mfma_peak_bare_loop.txt).
+// Layouts (lane l: j = l % 32, hh = l / 32):
+//   GEMM1  D1[u][m] = sum_k W1[ch 32 + u][k] x[m][k]:  A fragment ks = W1 row j, k = 16 ks + 8 hh .. + 8 (the swizzled chunk image of the 16x16 kernel, read as
+//          chunk (2 ks + hh) ^ (j & 15): conflict-free);  B fragment ks = x row j, the same k (resident);  accumulator register r = hidden unit 8 (r / 4) + 4 hh + r % 4 of row j.
+//   GELU   on register pairs (r, r + 1): the packed results hw[0..7] are 16 hidden units of row j.
+//   GEMM2  D2[c][m] += sum_u W2[c][u] h[m][u] in two K blocks of 16: the B fragment of block kb is hw[4 kb .. 4 kb + 3] AS IT STANDS when K slot (kb, hh, e) stands for
+//          hidden unit 16 kb + 8 (e / 4) + 4 hh + e % 4: the host stores W2 with its columns in that order (gp_convnext_mlp_pack_w2_s32).  A fragment (cb, kb) = W2p row 32 cb + j,
+//          16-byte chunk 2 kb + hh of the chunk's 64 bytes (the 16x16 kernel's image and swizzle).  Accumulator register r of block cb = channel 32 cb + 8 (r / 4) + 4 hh + r % 4 of row j.
+// Ring, barrier, DMA, epilogue slab: as convnext_mlp_kernel.  Packed-fp16 GELU only.
+typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GP_MLP_S32_WGS
+#define GP_MLP_S32_WGS 2       // workgroups per CU of the 4-wave form (3 needs <= 168 registers: the first build spilled 8)
+#endif
+template <int C, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? GP_MLP_S32_WGS : 1) void convnext_mlp_s32_kernel(const MlpKP p) {
+    constexpr int HD = 4 * C, NCH = HD / 32, KS = C / 16, CB = C / 32;
+    constexpr int ROWB = C * 2;
+    constexpr int W1B = 32 * ROWB, W2B = C * 64;
+    constexpr int STAGE = W1B + W2B, NS = (NWV == 4 && GP_MLP_S32_WGS == 3) ? 3 : 4, LEAD = NS - 1;
+    constexpr int I1 = W1B / 1024 / NWV, I2 = W2B / 1024 / NWV, G = I1 + I2;
+    constexpr int CPR1 = ROWB / 16, RPI1 = 64 / CPR1;
+    constexpr int PITCH = ROWB + 16, SLAB = 32 * PITCH;
+    constexpr int RING = NS * STAGE, SMEM = (RING + HD * 4) > NWV * SLAB ? (RING + HD * 4) : NWV * SLAB;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+    const long m0 = (long)xcd_chunk(blockIdx.x, gridDim.x) * (NWV * 32) + wave * 32;
+
+    float* b1s = reinterpret_cast<float*>(smem + RING);
+    for (int i = tid; i < HD / 4; i += NWV * 64) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(p.b1)[i];
+
+    uint4 xf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const uint4*>(p.X + (m0 + j) * C + ks * 16 + hh * 8);
+
+    unsigned w1off[I1], w2off[I2];
+#pragma unroll
+    for (int i = 0; i < I1; ++i) {
+        const int r = (i * NWV + wave) * RPI1 + lane / CPR1, pc = lane % CPR1;
+        w1off[i] = (unsigned)((r * C + ((pc ^ (r & 15)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < I2; ++i) {
+        const int lr = lane >> 2, r = (i * NWV + wave) * 16 + lr;
+        w2off[i] = (unsigned)((r * HD + (((lane & 3) ^ ((-(lr >> 2)) & 3)) << 3)) * 2);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)smem;
+    auto stage = [&](int buf, int ch) {
+        const unsigned s1 = lds0 + buf * STAGE + wave * 1024, s2 = s1 + W1B;
+        const char* b1p = reinterpret_cast<const char*>(p.W1) + (long)ch * W1B;
+        const char* b2p = reinterpret_cast<const char*>(p.W2p) + (long)ch * 64;
+#pragma unroll
+        for (int i = 0; i < I1; ++i) glds16_sb(b1p, w1off[i], s1 + i * NWV * 1024);
+#pragma unroll
+        for (int i = 0; i < I2; ++i) glds16_sb(b2p, w2off[i], s2 + i * NWV * 1024);
+    };
+
+    mlp_f32x16 acc2[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + cb * 32 + g * 8 + hh * 4);
+            acc2[cb][4 * g] = b[0]; acc2[cb][4 * g + 1] = b[1]; acc2[cb][4 * g + 2] = b[2]; acc2[cb][4 * g + 3] = b[3];
+        }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < LEAD; ++i) stage(i, i);
+
+    const int w1fo = j * ROWB, w2fo = j * 64, w2sw = (-((j & 15) >> 2)) & 3;
+    int buf = 0, nbuf = LEAD;
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (LEAD >= 3 && ch + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+        else if (LEAD >= 2 && ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + LEAD < NCH && p.dbg != 2) stage(nbuf, ch + LEAD);
+        const char* s1 = smem + buf * STAGE + w1fo;
+        const char* s2 = smem + buf * STAGE + W1B + w2fo;
+
+        mlp_f32x16 acc1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(b1s + ch * 32 + g * 8 + hh * 4);
+            acc1[4 * g] = b[0]; acc1[4 * g + 1] = b[1]; acc1[4 * g + 2] = b[2]; acc1[4 * g + 3] = b[3];
+        }
+        // ---- GEMM1, W1 fragments four k-steps at a time
+        constexpr int GK = C == 128 ? 2 : 1;       // (register budget: 168 at three workgroups per CU / 256 with 128 accumulators + 64 of x)
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += GK) {
+            uint4 a1[GK];
+#pragma unroll
+            for (int ks = 0; ks < GK; ++ks) a1[ks] = *reinterpret_cast<const uint4*>(s1 + (((2 * (k0 + ks) + hh) ^ (j & 15)) << 4));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < GK; ++ks)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&a1[ks]), *reinterpret_cast<const half8*>(&xf[k0 + ks]), acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- W2 fragments of K block 0 land under the GELU
+        constexpr int GC = 2;
+        uint4 a2[GC];
+#pragma unroll
+        for (int cb = 0; cb < GC; ++cb) a2[cb] = *reinterpret_cast<const uint4*>(s2 + cb * 2048 + ((hh ^ w2sw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned hw[8];
+        if (p.dbg == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hw[i] = __builtin_bit_cast(unsigned, half2v{(half_t)acc1[2 * i], (half_t)acc1[2 * i + 1]});
+        } else {        // four chains at a time (register budget)
+            f32x2 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = f32x2{acc1[2 * i], acc1[2 * i + 1]};
+            gelu16_xn<4>(v, hw);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = f32x2{acc1[8 + 2 * i], acc1[8 + 2 * i + 1]};
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "v"(hw[0]), "v"(hw[1]), "v"(hw[2]), "v"(hw[3]));
+            gelu16_xn<4>(v, hw + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- GEMM2
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const uint4 hb = uint4{hw[4 * kb], hw[4 * kb + 1], hw[4 * kb + 2], hw[4 * kb + 3]};
+#pragma unroll
+            for (int c0 = 0; c0 < CB; c0 += GC) {
+                if (kb > 0 || c0 > 0) {
+#pragma unroll
+                    for (int cb = 0; cb < GC; ++cb) a2[cb] = *reinterpret_cast<const uint4*>(s2 + (c0 + cb) * 2048 + (((2 * kb + hh) ^ w2sw) << 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int cb = 0; cb < GC; ++cb)
+                    acc2[c0 + cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8*>(&a2[cb]), *reinterpret_cast<const half8*>(&hb), acc2[c0 + cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
+    __syncthreads();
+
+    // ---- epilogue: gamma, fp16, transpose through the wave's slab, residual, whole rows
+    constexpr int LPR = ROWB / 16, RPS = 64 / LPR, NIT = 32 / RPS;
+    const int rr = lane / LPR, rc = lane % LPR;
+    half8 rres[NIT];
+    if constexpr (C == 128) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
+    }
+    char* slab = smem + wave * SLAB;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = cb * 32 + g * 8 + hh * 4;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            half4 o;
+            o[0] = (half_t)(acc2[cb][4 * g] * gm[0]); o[1] = (half_t)(acc2[cb][4 * g + 1] * gm[1]);
+            o[2] = (half_t)(acc2[cb][4 * g + 2] * gm[2]); o[3] = (half_t)(acc2[cb][4 * g + 3] * gm[3]);
+            *reinterpret_cast<half4*>(slab + j * PITCH + c * 2) = o;
+        }
+    if constexpr (C != 128) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) rres[i] = *reinterpret_cast<const half8*>(p.res + (m0 + i * RPS + rr) * C + rc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        half8 v = *reinterpret_cast<const half8*>(slab + (i * RPS + rr) * PITCH + rc * 16);
+        v += rres[i];
+        *reinterpret_cast<half8*>(p.out + (m0 + i * RPS + rr) * C + rc * 8) = v;
+    }
+}
+
+// =====================================================================================================
 // The same block for C = 512 (ConvNeXt stage 2: 27 of the 36 blocks; round 5), ONE wave per SIMD.
 // The two-launch path runs fc1 on the weights-in-registers kernel and fc2 on the ping-pong tile kernel: 134 MB of hidden activations
 // (128 crops) are stored and fetched again, both kernels pay a prologue / epilogue with the matrix pipe idle, and fc2's 256 epilogues hit
@@ -542,7 +725,27 @@ __global__ void mlp_pack_w2_kernel(const half_t* w2, half_t* w2p, int C, int HD)
     w2p[i] = w2[(long)c * HD + blk * 32 + nt * 16 + fq * 4 + j];
 }
 
+// the 32x32x16 kernel's order: inside every block of 32 hidden units, K slot s = kb*16 + hh*8 + e takes unit 16 kb + 8 (e / 4) + 4 hh + e % 4
+__global__ void mlp_pack_w2_s32_kernel(const half_t* w2, half_t* w2p, int C, int HD) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)C * HD) return;
+    const int c = (int)(i / HD), s = (int)(i - (long)c * HD);
+    const int blk = s >> 5, t = s & 31, kb = t >> 4, hh = (t >> 3) & 1, e = t & 7;
+    w2p[i] = w2[(long)c * HD + blk * 32 + 16 * kb + 8 * (e >> 2) + 4 * hh + (e & 3)];
+}
+
 }  // namespace
+
+extern "C" int gp_convnext_mlp_pack_w2_s32(const void* w2, void* w2p, int C, void* stream) {
+    GP_REQUIRE(w2 && w2p && w2 != w2p, "gp_convnext_mlp_pack_w2_s32: bad pointers");
+    GP_REQUIRE(C == 128 || C == 256, "gp_convnext_mlp_pack_w2_s32: C=%d must be 128 or 256", C);
+    const long n = (long)C * 4 * C;
+    hipLaunchKernelGGL(mlp_pack_w2_s32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const half_t*>(w2), reinterpret_cast<half_t*>(w2p), C, 4 * C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gp_fail(GP_ERR_LAUNCH, "gp_convnext_mlp_pack_w2_s32: %s", hipGetErrorString(e));
+    return GP_OK;
+}
 
 extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream) {
     GP_REQUIRE(w2 && w2p && w2 != w2p, "gp_convnext_mlp_pack_w2: bad pointers");
@@ -556,8 +759,11 @@ extern "C" int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* s
 }
 
 extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
-                               const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream) {
+                               const float* gamma, const void* residual, void* out, long M, int C, int dtype_in, void* stream) {
+    const bool s32 = (dtype_in & GP_MLP_S32) != 0;     // w2p in gp_convnext_mlp_pack_w2_s32's order: the 32x32x16 kernel
+    const int dtype = dtype_in & ~GP_MLP_S32;
     GP_REQUIRE(dtype == GP_F16, "gp_convnext_mlp: fp16 storage only (fp32 runs fc1 / fc2 through gp_gemm)");
+    GP_REQUIRE(!s32 || (C == 128 && gp_gelu16_enabled()), "gp_convnext_mlp: GP_MLP_S32 exists for C = 128 with the packed-fp16 GELU");
     GP_REQUIRE(C == 128 || C == 256 || C == 512, "gp_convnext_mlp: C=%d must be 128, 256 or 512", C);
     GP_REQUIRE(x && w1 && b1 && w2p && b2 && gamma && residual && out, "gp_convnext_mlp: null operand");
     GP_REQUIRE(M > 0 && M % (C == 512 ? 128 : 256) == 0, "gp_convnext_mlp: M=%ld must be a positive multiple of %d", M, C == 512 ? 128 : 256);
@@ -578,6 +784,12 @@ extern "C" int gp_convnext_mlp(const void* x, const void* w1, const float* b1, c
         const dim3 grid512((unsigned)(M / 128));
         GP_REQUIRE(gp_gelu16_enabled(), "gp_convnext_mlp: the C = 512 kernel exists with the packed-fp16 GELU only (GP_GELU16=0: run fc1 / fc2 through gp_gemm)");
         hipLaunchKernelGGL(convnext_mlp512_kernel, grid512, dim3(256), 0, s, p);
+        GP_LAUNCH_CHECK("gp_convnext_mlp");
+    }
+    if (s32) {
+        gp_timing_label("convnext_mlp s32 C%d M%ld", C, M);
+        GP_REQUIRE(C == 128, "gp_convnext_mlp: GP_MLP_S32 is built for C = 128 (C = 256 needs 128 accumulator + 64 x registers beside a 16-register GEMM1 accumulator: it spilled 55)");
+        hipLaunchKernelGGL((convnext_mlp_s32_kernel<128, 4>), dim3((unsigned)(M / 128)), dim3(256), 0, s, p);
         GP_LAUNCH_CHECK("gp_convnext_mlp");
     }
     const dim3 grid((unsigned)(M / 256));

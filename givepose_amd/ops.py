@@ -382,18 +382,22 @@ def convnext_stem(img, w, b, ln_w, ln_b, out, eps=1e-6):
     return out
 
 
-def convnext_mlp_pack_w2(w2):
-    """fc2.weight (C, 4C) fp16 -> the column order gp_convnext_mlp reads (include/givepose_hip.h)."""
+MLP_S32 = 0x400        # include/givepose_hip.h GP_MLP_S32
+
+
+def convnext_mlp_pack_w2(w2, s32=False):
+    """fc2.weight (C, 4C) fp16 -> the column order gp_convnext_mlp reads (include/givepose_hip.h); s32: the order of its 32x32x16-MFMA form."""
     out = torch.empty_like(w2)
-    check(_L().gp_convnext_mlp_pack_w2(_ptr(_contig(w2, "w2")), _ptr(out), w2.shape[0], _stream()), "gp_convnext_mlp_pack_w2")
+    fn = _L().gp_convnext_mlp_pack_w2_s32 if s32 else _L().gp_convnext_mlp_pack_w2
+    check(fn(_ptr(_contig(w2, "w2")), _ptr(out), w2.shape[0], _stream()), "gp_convnext_mlp_pack_w2")
     return out
 
 
-def convnext_mlp(x, w1, b1, w2p, b2, gamma, residual, out):
-    """out = residual + gamma * fc2(GELU(fc1(x))) in one launch (fp16, C in {128, 256}); out may alias residual."""
+def convnext_mlp(x, w1, b1, w2p, b2, gamma, residual, out, s32=False):
+    """out = residual + gamma * fc2(GELU(fc1(x))) in one launch (fp16, C in {128, 256}); out may alias residual.  s32: w2p was packed with s32=True."""
     M, C = x.shape
     check(_L().gp_convnext_mlp(_ptr(_contig(x, "x")), _ptr(w1), _ptr(b1), _ptr(w2p), _ptr(b2), _ptr(gamma), _ptr(residual),
-                               _ptr(out), M, C, dtype_code(x.dtype), _stream()), "gp_convnext_mlp")
+                               _ptr(out), M, C, dtype_code(x.dtype) | (MLP_S32 if s32 else 0), _stream()), "gp_convnext_mlp")
     return out
 
 

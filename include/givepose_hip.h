@@ -50,7 +50,7 @@ enum gp_epilogue {
 };
 
 const char* gp_last_error(void);
-#define GP_ABI_VERSION 322 /* round 6: + gp_dwconv_ln_groups (322); 321 = round 5: gp_gemm_desc.gn_rows + gp_gemm_gn_rows (321); gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
+#define GP_ABI_VERSION 323 /* round 6: + gp_dwconv_ln_groups (322), gp_convnext_mlp_pack_w2_s32 / GP_MLP_S32 (323); 321 = round 5: gp_gemm_desc.gn_rows + gp_gemm_gn_rows (321); gp_gemm variants 19-22, gp_convnext_mlp C = 512 (no layout change); 311 = round 4 (+ gp_groupnorm_upsample2x); 310 = round 3 (gp_gemm_desc: split-operand / fp32 residual stream fields); 200 = round 2 */
 int gp_version(void);   /* == GP_ABI_VERSION of the header the library was built from */
 /* device properties the host needs: CU count and arch string ("gfx950...") */
 int gp_device_info(int* cu_count, char* arch, int arch_len);
@@ -204,6 +204,9 @@ int gp_split_planes(const float* x, void* planes, long rows, int cols, long ldx,
  *   fragment that the GELU output forms in registers).  M % 256 == 0; all pointers 16-byte aligned.
  *   The GELU runs on packed fp16 arithmetic (common.hpp gelu16_slice) unless the environment has GP_GELU16=0. */
 int gp_convnext_mlp_pack_w2(const void* w2, void* w2p, int C, void* stream);
+/* round 6: the column order of the 32x32x16-MFMA form of gp_convnext_mlp (C = 128 / 256): pass GP_F16 | GP_MLP_S32 as `dtype` together with it */
+int gp_convnext_mlp_pack_w2_s32(const void* w2, void* w2p, int C, void* stream);
+#define GP_MLP_S32 0x400
 int gp_convnext_mlp(const void* x, const void* w1, const float* b1, const void* w2p, const float* b2,
                     const float* gamma, const void* residual, void* out, long M, int C, int dtype, void* stream);
 

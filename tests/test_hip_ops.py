@@ -477,6 +477,33 @@ def test_convnext_mlp_fused(C):
         o.convnext_mlp(dev(x, dt)[:100], dev(w1, dt), dev(b1), w2p, dev(b2), dev(gamma), out[:100], out[:100])
 
 
+def test_convnext_mlp_fused_s32_form():
+    """Round 6: the C = 128 fused MLP on v_mfma_f32_32x32x16_f16 (GP_MLP_S32; its own W2 column order): against the fp32 formula and the 16x16x32 kernel.
+    Measured slower (profiles/r06_mlp_s32_ab.txt), kept behind the flag; C = 256 is refused (it spilled)."""
+    o = ops()
+    dt = torch.float16
+    C, M = 128, 640
+    HD = 4 * C
+    x, res = q(rnd(M, C, seed=81), dt), q(rnd(M, C, seed=82), dt)
+    w1, b1 = q(rnd(HD, C, seed=83, scale=C ** -0.5), dt), rnd(HD, seed=84)
+    w2, b2 = q(rnd(C, HD, seed=85, scale=HD ** -0.5), dt), rnd(C, seed=86)
+    gamma = rnd(C, seed=87)
+    ref = res + gamma * (q(F.gelu(x @ w1.t() + b1), dt) @ w2.t() + b2)
+    dev = lambda t, d=None: t.to("cuda", d) if d else t.cuda()
+    outs = []
+    for s32 in (False, True):
+        out = dev(res, dt).clone()
+        o.convnext_mlp(dev(x, dt), dev(w1, dt), dev(b1), o.convnext_mlp_pack_w2(dev(w2, dt), s32=s32), dev(b2), dev(gamma), out, out, s32=s32)
+        assert rel_err(out, ref) < 2e-3, s32
+        outs.append(out)
+    assert float((outs[0].float() - outs[1].float()).abs().max()) < 1e-2 * float(ref.abs().max())
+    from givepose_amd._lib import GivePoseHipError
+    w256 = torch.zeros(256, 1024, dtype=dt, device="cuda")
+    with pytest.raises(GivePoseHipError):
+        o.convnext_mlp(torch.zeros(256, 256, dtype=dt, device="cuda"), w256.t().contiguous(), torch.zeros(1024, device="cuda"), w256, torch.zeros(256, device="cuda"),
+                       torch.zeros(256, device="cuda"), torch.zeros(256, 256, dtype=dt, device="cuda"), torch.zeros(256, 256, dtype=dt, device="cuda"), s32=True)
+
+
 def test_dwconv7_raw_stats_and_lnfold_gemm():
     """LayerNorm deferred to the GEMM epilogue: dw7x7 raw output + slab moments, then fc1 with GP_EPI_LNFOLD_GELU must
     reproduce gelu(fc1(LayerNorm(dwconv(x)))) (the ConvNeXt block front half)."""
