@@ -482,7 +482,7 @@ def test_convnext_mlp_fused_s32_form():
     Measured slower (profiles/r06_mlp_s32_ab.txt), kept behind the flag; C = 256 is refused (it spilled)."""
     o = ops()
     dt = torch.float16
-    C, M = 128, 640
+    C, M = 128, 768          # (three 4-wave workgroups of the s32 form, a multiple of the 16x16 kernel's 256 rows)
     HD = 4 * C
     x, res = q(rnd(M, C, seed=81), dt), q(rnd(M, C, seed=82), dt)
     w1, b1 = q(rnd(HD, C, seed=83, scale=C ** -0.5), dt), rnd(HD, seed=84)
