@@ -141,7 +141,7 @@ AUTO_SPLITK = True
 CO_SCHEDULED = False
 
 
-def auto_splitk(M, N, K, esz, n_cu=256):
+def auto_splitk(M, N, K, esz, n_cu=256, plain=True):
     """Split only long-K GEMMs with a handful of tiles (the PnP fc1: 16 tiles, 128 K steps -> 16 ranges, 85 -> 22 us);
     measured on MI355X (scripts/splitk_bench.py): with >= 32 tiles or < 32 K steps the reduce kernel costs more than the
     split saves (feat_reducer 14.6 -> 22.7 us, fc2 16.7 -> 16.3 us)."""
@@ -149,7 +149,8 @@ def auto_splitk(M, N, K, esz, n_cu=256):
     nkt = K // (128 // esz)
     # round 6 (scripts/stage3_splitk.py, profiles/r06_stage3_splitk.txt): ConvNeXt stage-3 fc2 (N = 1024, K = 4096) at 16 .. 32 crops is 64 .. 128 tiles of 128 x 128
     # with a 64-step K loop on a quarter to a half of the chip: four K ranges + the reduce kernel 43.6 -> 28.1 / 43.9 -> 31.4 / 43.9 -> 33.9 us (from 192 tiles: nothing)
-    if esz == 2 and K >= 4096 and 32 < tiles <= 128:
+    # (plain GEMMs only: measured on that shape; the ResNet-34 variant's 3x3 x 512 convs have K = 4 608 and were not)
+    if plain and esz == 2 and K >= 4096 and 32 < tiles <= 128:
         return 4
     if tiles >= 32 or nkt < 32:
         return 1
@@ -223,7 +224,7 @@ def gemm(x, w, out, bias=None, epilogue=EPI_NONE, gamma=None, residual=None, M=N
     if (x_planes or out_planes) and not split:
         raise RuntimeError("gemm: x_planes / out_planes belong to the split-operand mode")
     if splitk is None:
-        splitk = auto_splitk(M, N, K, esz) if (AUTO_SPLITK and variant in (0, 4) and gn is None and ln is None) else 1
+        splitk = auto_splitk(M, N, K, esz, plain=conv is None) if (AUTO_SPLITK and variant in (0, 4) and gn is None and ln is None) else 1
     d.X, d.W, d.C = xptr, w.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.gamma = gamma.data_ptr() if gamma is not None else None
