@@ -759,12 +759,16 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
 #define GP_WAIT_VMCNT_J(J) do { if constexpr ((J) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else { static_assert((J) == 9, "J"); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); } } while (0)
 // TH = 4 (16-wide maps only): quarter-image tiles for the launches whose half-image tiles would leave half the chip idle (33 .. 64 crops at stage 2: the
 // strictly serial bs-64 forward): two row pairs per wave -- the B-fragment sharing is gone (4 fragments for 4 MFMAs per column shift) -- everything else as above.
-template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
+// PAIR (8 x 8 maps: ConvNeXt stage 3, C = 1024): TWO images side by side in one 16-column tile -- lane n of a B fragment is column n & 7 of image n >> 3, the pixel
+// slots of a row are [image A: 8][image B: 8][zero][zero] and a column outside its OWN image reads a zero pixel (the same swizzle stays conflict-free:
+// scripts/probes/dw_tall_swizzle.py); TH = 4 (128 accumulator registers at 16 slabs).  The images of a pair are consecutive in memory.
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8, bool PAIR = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
 __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
                                                                  const float* __restrict__ bias, const float* __restrict__ lnw,
                                                                  const float* __restrict__ lnb, half_t* __restrict__ y, int H, int Wrt, float eps) {
     constexpr int C = 64 * NS, NP = TH / 2, IH = TH + 6, PITCH = WIDE ? 22 : 18, ROWB = PITCH * 128, NPX = 16 * TH, NBF = NP + 2;
     static_assert(TH == 8 || (TH == 4 && !WIDE), "tile height");
+    static_assert(!PAIR || (!WIDE && TH == 4), "pair tiles: 8-wide maps, quarter... half-image tiles of two images");
     constexpr int IN_BYTES = (IH * ROWB + 1023) / 1024 * 1024, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024;   // PAD_OFF: 1 KB, target of the padding DMA instructions
     // WIDE: ONE stage and two workgroups per CU (<= 128 registers, 57-59 KB of LDS each): a map of 64 x 64 is many rounds of tiles, so it is another
     // workgroup's conv that covers this one's prologue, slab latency and epilogue, not a ring inside the workgroup (measured: one workgroup per CU with a
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     constexpr int PAR_OFF = (OUT_BYTES > NST * STAGE ? OUT_BYTES : NST * STAGE), PAR_INS = (3 * C * 4 + 1023) / 1024;
     constexpr int RED_OFF = PAR_OFF + PAR_INS * 1024;          // [2][8 waves][128 px] fp32
     static_assert(RED_OFF + 2 * 8 * NPX * 4 <= 160 * 1024, "LDS");
-    static_assert(PAR_INS <= 8, "one parameter DMA instruction per wave");
+    static_assert(PAR_INS <= 16, "at most two parameter DMA instructions per wave");
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     const unsigned lds0 = (unsigned)(size_t)(lds_char_t*)dsm;
@@ -819,7 +823,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
         } else if (!WIDE && i < nin) {
             const int r = rlo + (i >> 1), cc = (i & 1) * 8 + (lane >> 3), o = (lane & 7) ^ ((cc >> 1) & 7);
             sb = (unsigned long long)xb;
-            vo = (unsigned)((((h0 - 3 + r) * W + cc) * C + o * 8) * 2);
+            vo = PAIR ? (unsigned)((((i & 1) * H * 8 + (h0 - 3 + r) * 8 + (lane >> 3)) * C + o * 8) * 2)      // piece (r, half) = row r of image `half` of the pair
+                      : (unsigned)((((h0 - 3 + r) * W + cc) * C + o * 8) * 2);
             ds = (unsigned)((r * PITCH + (i & 1) * 8) * 128);
         } else if (i < nin + 7) {
             const int t7 = i - nin, tap = min(t7 * 8 + (lane >> 3), 48), kh = (tap * 37) >> 8, ch = (lane & 7) ^ kh;   // tap / 7 for tap < 56
@@ -834,10 +839,11 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     };
     // slab 0 and the parameters by ALL eight waves, first thing in the kernel (the launch is one round of workgroups: nothing hides this
     // latency); slabs 1 and 2 follow from the loading waves behind the first barrier
-    if (wave < PAR_INS) {
-        const int f = (wave * 64 + lane) * 4;
+#pragma unroll
+    for (int ins = wave; ins < PAR_INS; ins += 8) {
+        const int f = (ins * 64 + lane) * 4;
         const float* src = f < C ? bias + f : (f < 2 * C ? lnw + (f - C) : lnb + (f - 2 * C));
-        glds16_n(f < 3 * C ? (const void*)src : (const void*)gp_zero_page_tu, __builtin_amdgcn_readfirstlane(lds0 + PAR_OFF + wave * 1024));
+        glds16_n(f < 3 * C ? (const void*)src : (const void*)gp_zero_page_tu, __builtin_amdgcn_readfirstlane(lds0 + PAR_OFF + ins * 1024));
     }
 #pragma unroll
     for (int j = 0; j < (WIDE ? J : (J + 1) / 2); ++j) {
@@ -904,9 +910,15 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     unsigned sw[7];       // byte offset of this lane's B slot for column shift kw (row block 0): row q, column n + kw - 3
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw) {
+        if constexpr (PAIR) {
+            const int c = (n & 7) + kw - 3, cs = (n >> 3) * 8 + c;      // column of the lane's own image; slot in the row
+            const int cc = (unsigned)c < 8u ? cs : 16 + (cs & 1);
+            sw[kw] = (unsigned)(q * ROWB + cc * 128 + (((wave ^ (cs >> 1)) & 7) << 4));
+        } else {
         const int c = WIDE ? n + kw : n + kw - 3;      // WIDE: halo column
         const int cc = (WIDE || (unsigned)c < 16u) ? c : 16 + (c & 1);
         sw[kw] = (unsigned)(q * ROWB + cc * 128 + (((wave ^ (c >> 1)) & 7) << 4));
+        }
     }
     const int kh0 = q - ar, kh1 = q + 4 - ar;
     const int kh0c = kh0 < 0 ? 0 : kh0, kh1c = kh1 > 6 ? 6 : kh1;
@@ -1073,7 +1085,7 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     }
     char* out_s = dsm;
     constexpr int cpp = C / 8;   // 16-byte chunks per pixel
-    half_t* yb = y + (((long)b * H + h0) * W + w0) * C;
+    half_t* yb = PAIR ? y + ((long)b * 2 * H + h0) * 8 * C : y + (((long)b * H + h0) * W + w0) * C;      // PAIR: b = pair index
     // two halves (TH = 8: row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -1103,7 +1115,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
         for (int i = tid; i < (NPX / 2) * cpp; i += 512) {
             const int px = hf * (NPX / 2) + i / cpp, c = i % cpp;
             const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
-            *reinterpret_cast<uint4*>(yb + ((long)(px >> 4) * W + (px & 15)) * C + c * 8) = v;
+            if constexpr (PAIR) *reinterpret_cast<uint4*>(yb + ((long)((px & 15) >> 3) * H * 8 + (px >> 4) * 8 + (px & 7)) * C + c * 8) = v;
+            else *reinterpret_cast<uint4*>(yb + ((long)(px >> 4) * W + (px & 15)) * C + c * 8) = v;
         }
     }
     GP_DWT_MARK(46);
@@ -1113,17 +1126,17 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
 #endif
 }
 
-template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8>
+template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8, bool PAIR = false>
 void launch_dw7_tall(const void* x, const void* wt, const float* bias, const float* lnw, const float* lnb, void* y, int B, int H, int W,
                      float eps, hipStream_t s) {
     constexpr int C = 64 * NS, NST = WIDE ? 1 : (NS >= 3 ? 3 : NS), STAGE = ((TH + 6) * (WIDE ? 22 : 18) * 128 + 1023) / 1024 * 1024 + 8 * 1024, OUTB = 16 * TH * C * 2;
     constexpr int PAR_OFF = (OUTB > NST * STAGE ? OUTB : NST * STAGE), LDS = PAR_OFF + ((3 * C * 4 + 1023) / 1024) * 1024 + 2 * 8 * 16 * TH * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH>), dim3(B * (H / TH) * (W / 16)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
+    hipLaunchKernelGGL((dwconv7_ln_tall_kernel<NS, J, WIDE, NOMFMA, TH, PAIR>), dim3(PAIR ? (B / 2) * (H / TH) : B * (H / TH) * (W / 16)), dim3(512), LDS, s, (const half_t*)x, (const half_t*)wt, bias,
                        lnw, lnb, (half_t*)y, H, W, eps);
 }
 
@@ -1704,6 +1717,10 @@ static long dw_tallw_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_TALLW_MIN"); return e ? atol(e) : -1l; }();
     return k >= 0 ? k : C == 128 ? 384 : 256;
 }
+static long dw_pair_min_crops() {     // the pair-tile form at stage 3 (GP_DW_PAIR_MIN: A/B; a huge value switches it off)
+    static const long k = [] { const char* e = getenv("GP_DW_PAIR_MIN"); return e ? atol(e) : 32l; }();
+    return k;
+}
 static bool dw_tall4_enabled() {     // GP_DW_TALL4=0: A/B switch for the quarter-image form
     static const bool on = [] { const char* e = getenv("GP_DW_TALL4"); return !(e && e[0] == '0'); }();
     return on;
@@ -1755,6 +1772,12 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
             else if (C == 256) launch_dw7_tall<4, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
             else launch_dw7_tall<8, 9>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         }
+        GP_LAUNCH_CHECK("gp_dwconv_ln");
+    }
+    // 8 x 8 maps at C = 1024 (ConvNeXt stage 3): two images per 16-column tile, from dw_pair_min_crops() crops up (even batch); act code 113 forces it
+    if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && W == 8 && H % 4 == 0 && C == 1024 && B % 2 == 0 && x != y &&
+        (dbg == 13 || (dbg == 0 && B >= dw_pair_min_crops()))) {
+        launch_dw7_tall<16, 8, false, false, 4, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
     // quarter-image tiles (TH = 4) of 16-wide maps where the half-image tiles would leave the chip half empty (33 .. 64 crops at stage 2); act code 112 forces it

@@ -54,3 +54,25 @@ def conflicts2():
                     worst = max(worst, m); tot += sum(len(v) - 1 for v in seen.values())
     return worst, tot
 print("pitch 18, two zero pixels:", conflicts2())
+
+def conflicts_pair():
+    """two 8-wide images side by side in one 16-column tile (stage 3, 8 x 8 maps): lane n -> image n >> 3, column (n & 7) + kw - 3; slot = image * 8 + column"""
+    worst = 0; tot = 0
+    for w in range(8):
+        for kw in range(7):
+            for rb in range(0, 7):
+                for g in groups:
+                    seen = {}
+                    for l in g:
+                        n, q = l & 15, l >> 4
+                        r = rb + q
+                        c = (n & 7) + kw - 3
+                        cs = (n >> 3) * 8 + c
+                        cc = cs if 0 <= c < 8 else 16 + (cs & 1)
+                        P = r * 18 + cc
+                        addr = P * 8 + (w ^ ((cs >> 1) & 7))
+                        seen.setdefault(addr % 16, set()).add(addr)
+                    m = max(len(v) for v in seen.values())
+                    worst = max(worst, m); tot += sum(len(v) - 1 for v in seen.values())
+    return worst, tot
+print("pair tiles (two 8-wide images), pitch 18:", conflicts_pair())

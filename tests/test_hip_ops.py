@@ -713,14 +713,17 @@ def test_dwconv_ln_fp16_kernels_by_grid_size(C, H, KS, B, offset):
 
 @pytest.mark.parametrize("C,H,B,offset,W", [(512, 16, 3, 0.0, 16), (512, 16, 128, 0.0, 16), (256, 16, 5, 0.0, 16), (128, 16, 2, 0.0, 16), (512, 8, 2, 0.0, 16),
                                             (512, 32, 2, 0.0, 16), (256, 24, 1, 0.0, 16), (512, 16, 7, 5.0, 16),
-                                            (128, 64, 2, 0.0, 64), (256, 32, 3, 0.0, 32), (128, 24, 1, 0.0, 48), (256, 8, 2, 0.0, 32), (128, 64, 1, 5.0, 64)])
+                                            (128, 64, 2, 0.0, 64), (256, 32, 3, 0.0, 32), (128, 24, 1, 0.0, 48), (256, 8, 2, 0.0, 32), (128, 64, 1, 5.0, 64),
+                                            (1024, 8, 2, 0.0, 8), (1024, 8, 6, 5.0, 8), (1024, 8, 64, 0.0, 8), (1024, 16, 2, 0.0, 8)])
 def test_dwconv_ln_tall_tiles(C, H, B, offset, W):
     """dwconv7_ln_tall_kernel (round 6: 16 x 8 tiles of 16-pixel-wide maps, zero pixels in LDS instead of a halo, three-stage slab ring):
     forced with act code 110 at grids the routing would not send it (it takes over from 130 half-image workgroups), against the fp32
     reference and against the 16 x 4 / strip kernels on the same input; H = 8 (one tile, zero rows above AND below), H = 16 (the
     product shape), H = 24 / 32 (interior tiles with 14 real halo rows: the five-instruction DMA plan); offset 5: |mean| ~ 50 std."""
     # W > 16: the column-halo form (stages 0 / 1 of the trunk): edge tiles on every side, interior tiles (64 x 64), a non-square map, a one-tile-high map
+    # W = 8, C = 1024 (stage 3; act code 113): two images side by side in one tile -- neither may see the other's columns; H = 16: interior-row tiles
     o = ops()
+    force = 113 if W == 8 else 110
     dt = torch.float16
     x = q(rnd(B, C, H, W, seed=140), dt)
     w = q(rnd(C, 1, 7, 7, seed=141, scale=(0.02 if offset else 1.0) / 7), dt)
@@ -730,15 +733,16 @@ def test_dwconv_ln_tall_tiles(C, H, B, offset, W):
     xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
     wd = w.reshape(C, 49).t().contiguous().to("cuda", dt)
     out = torch.zeros(B, H, W, C, dtype=dt, device="cuda")
-    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out, 7, act=110)
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out, 7, act=force)
     assert rel_err(out, ref) < (2 * TOL[dt] if offset else TOL[dt]), rel_err(out, ref)
     old = torch.zeros_like(out)
     o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), old, 7)       # below 130 workgroups the routing takes the older kernels
     if B * (H // 8) * (W // 16) < 130:
         assert float((out.float() - old.float()).abs().max()) <= 4e-3 * max(1.0, float(ref.abs().max()))
     out2 = torch.zeros_like(out)      # bitwise repeatable
-    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2, 7, act=110)
-    assert torch.equal(out, out2)
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2, 7, act=force)
+    nz = (out != out2).nonzero()
+    assert nz.shape[0] == 0, (nz.shape[0], nz[:8].tolist(), float((out.float() - out2.float()).abs().max()), float((out2.float() - ref.cuda()).abs().max()), float((out.float() - ref.cuda()).abs().max()))
     if W == 16:                       # the quarter-image form (TH = 4; act code 112): what a launch of 33 .. 64 crops at stage 2 takes
         out4 = torch.zeros_like(out)
         o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out4, 7, act=112)
