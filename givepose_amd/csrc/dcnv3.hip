@@ -32,10 +32,15 @@ template <typename T> struct Ch4;  // 4 channels of T
 template <> struct Ch4<half_t> {
     half4 v;
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    // fma(a, v[i], c): one v_fma_mix_f32 (the fp16 operand is read straight from its half of the packed register; the compiler finds it by itself)
+    __device__ __forceinline__ float fma(float a, int i, float c) const { return fmaf(a, (float)v[i], c); }
+    __device__ __forceinline__ float mul(float a, int i) const { return a * (float)v[i]; }
 };
 template <> struct Ch4<float> {
     f32x4 v;
     __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ float mul(float a, int i) const { return a * v[i]; }
+    __device__ __forceinline__ float fma(float a, int i, float c) const { return fmaf(a, v[i], c); }
 };
 template <typename T> __device__ __forceinline__ Ch4<T> ld4(const T* p) {
     Ch4<T> c;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
 // overlapping input pixels, and one group's share of an input pixel is a single 128-byte line, so the patch's footprint
 // (about 10 x 10 input pixels = 13 KB) stays in the CU's 32-KB L1: the wave-per-pixel mapping below pulls every one of its
 // 36 x 512 gathered bytes from L2 (1.2 GB per launch at 64 x 64 = 4.7 MB per CU, i.e. the ~55 GB/s a CU gets from L2).
-template <typename T, typename OT, int KS = 0, bool PATCH = false>
+template <typename T, typename OT, int KS = 0, bool PATCH = false, bool FOLD = true>     // FOLD = false: A/B arm (GP_DCN_FOLD=0), see MW below
 __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     static_assert(!PATCH || KS == 3, "patch mapping: 3 x 3 only");
     const int lane = threadIdx.x & 63;
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
         // repeated the ~70 instructions of coordinate arithmetic per tap in every lane: 1 100 VALU instructions per
         // output pixel, which is what bounded the kernel (ablation: 58 of 120 us with every load removed).
         static_assert(KS == 3, "row_share immediates are spelled out for 3x3");
+        constexpr bool MW = sizeof(T) == 2 && FOLD;
         const float Hf = (float)p.H, Wf = (float)p.W;
         const char* imb = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) +
                                                         (long)__builtin_amdgcn_readfirstlane(b) * p.H * p.W * 256);
@@ -243,23 +249,31 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
             w3 = (hhi && wl) ? lh * hw : 0.f;
             w4 = (hhi && whi) ? lh * lw : 0.f;
             const int y0 = max(h_low, 0), y1 = min(h_high, p.H - 1), x0 = max(w_low, 0), x1 = min(w_high, p.W - 1);
+            if constexpr (MW) { w1 *= mk; w2 *= mk; w3 *= mk; w4 *= mk; }
             o00 = (unsigned)((y0 * p.W + x0) * 256) * (unsigned)sizeof(T);
             dx = (unsigned)((x1 - x0) * 256) * (unsigned)sizeof(T);
             dy = (unsigned)((y1 - y0) * p.W * 256) * (unsigned)sizeof(T);
         }
         const unsigned lo = (unsigned)cl * 4u * (unsigned)sizeof(T);
-#define GP_RSF(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, false))
-#define GP_RSU(v, q) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (q), 0xF, 0xF, false)
+        // fp16 storage (MW): the mask weight is folded into the four corner weights by the tap's owner lane (4 multiplies per tap and ROW instead
+        // of one FMA per tap, channel and LANE, and one broadcast less); the fp32 instantiation keeps the reference's association
+        // ((w1 v1 + w2 v2 + w3 v3 + w4 v4) * mask, dcnv3_im2col_cuda.cuh:32-80) -- it is the parity mode
+#define GP_RSF(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, true))
+#define GP_RSU(v, q) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (q), 0xF, 0xF, true)
 #define GP_TAP(q)                                                                                              \
         {                                                                                                      \
-            const float a1 = GP_RSF(w1, q), a2 = GP_RSF(w2, q), a3 = GP_RSF(w3, q), a4 = GP_RSF(w4, q), wg = GP_RSF(mk, q); \
+            const float a1 = GP_RSF(w1, q), a2 = GP_RSF(w2, q), a3 = GP_RSF(w3, q), a4 = GP_RSF(w4, q), wg = MW ? 0.f : GP_RSF(mk, q); \
             const unsigned b00 = GP_RSU(o00, q) + lo, ex = GP_RSU(dx, q), ey = GP_RSU(dy, q);                  \
             const Ch4<T> v1 = ld4(reinterpret_cast<const T*>(imb + (size_t)b00)),                              \
                          v2 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ex))),                       \
                          v3 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ey))),                       \
                          v4 = ld4(reinterpret_cast<const T*>(imb + (size_t)(b00 + ex + ey)));                  \
+            if constexpr (MW) {                                                                                \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                  \
+                    acc[c] = v4.fma(a4, c, v3.fma(a3, c, v2.fma(a2, c, v1.fma(a1, c, acc[c]))));               \
+            } else                                                                                             \
             _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
-                float tt = a1 * v1.get(c);                                                                     \
+                float tt = v1.mul(a1, c);                                                                      \
                 tt = fmaf(a2, v2.get(c), tt);                                                                  \
                 tt = fmaf(a3, v3.get(c), tt);                                                                  \
                 tt = fmaf(a4, v4.get(c), tt);                                                                  \
@@ -292,6 +306,11 @@ static bool dcn_xcd_enabled() {   // GP_DCN_XCD=0: A/B switch for the XCD-contig
     return on;
 }
 
+static bool dcn_fold_enabled() {   // GP_DCN_FOLD=0: A/B switch (fp16: mask weight folded into the corner weights)
+    static const bool on = [] { const char* e = getenv("GP_DCN_FOLD"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
     static const bool on = [] { const char* e = getenv("GP_DCN_PATCH"); return !(e && e[0] == '0'); }();
     return on;
@@ -299,7 +318,8 @@ static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
 
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
     if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled()) {
-        hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
+        if (sizeof(T) == 2 && !dcn_fold_enabled()) hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true, false>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
     } else if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
     } else if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {
