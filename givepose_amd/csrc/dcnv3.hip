@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void dcnv3_generic_kernel(const DcnKP p) {
 // overlapping input pixels, and one group's share of an input pixel is a single 128-byte line, so the patch's footprint
 // (about 10 x 10 input pixels = 13 KB) stays in the CU's 32-KB L1: the wave-per-pixel mapping below pulls every one of its
 // 36 x 512 gathered bytes from L2 (1.2 GB per launch at 64 x 64 = 4.7 MB per CU, i.e. the ~55 GB/s a CU gets from L2).
-template <typename T, typename OT, int KS = 0, bool PATCH = false, bool FOLD = true>     // FOLD = false: A/B arm (GP_DCN_FOLD=0), see MW below
+template <typename T, typename OT, int KS = 0, bool PATCH = false, bool FOLD = false>     // FOLD = true: measurement arm (GP_DCN_FOLD=1), see MW below
 __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     static_assert(!PATCH || KS == 3, "patch mapping: 3 x 3 only");
     const int lane = threadIdx.x & 63;
@@ -255,9 +255,11 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
             dy = (unsigned)((y1 - y0) * p.W * 256) * (unsigned)sizeof(T);
         }
         const unsigned lo = (unsigned)cl * 4u * (unsigned)sizeof(T);
-        // fp16 storage (MW): the mask weight is folded into the four corner weights by the tap's owner lane (4 multiplies per tap and ROW instead
-        // of one FMA per tap, channel and LANE, and one broadcast less); the fp32 instantiation keeps the reference's association
-        // ((w1 v1 + w2 v2 + w3 v3 + w4 v4) * mask, dcnv3_im2col_cuda.cuh:32-80) -- it is the parity mode
+        // MW (fp16 storage, GP_DCN_FOLD=1 only): the mask weight folded into the four corner weights by the tap's owner lane (4 multiplies per tap and ROW
+        // instead of one FMA per tap, channel and LANE, and one broadcast less: 433 -> 392 VALU instructions per wave).  Measured: -2 % at 64 x 64, nothing
+        // below (profiles/r06_dcn_fold_ab.txt) -- the gather is bound by its line requests -- and another rounding of every gathered value, which the fp16
+        // mode's worst-conditioned crop can see (tests/test_grouped_launch.py: |dR| 2.0e-2 -> 3.8e-2 against a 3e-2 bound).  Not the default: every
+        // instantiation keeps the reference's association ((w1 v1 + w2 v2 + w3 v3 + w4 v4) * mask, dcnv3_im2col_cuda.cuh:32-80).
 #define GP_RSF(v, q) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + (q), 0xF, 0xF, true))
 #define GP_RSU(v, q) (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (q), 0xF, 0xF, true)
 #define GP_TAP(q)                                                                                              \
@@ -306,8 +308,8 @@ static bool dcn_xcd_enabled() {   // GP_DCN_XCD=0: A/B switch for the XCD-contig
     return on;
 }
 
-static bool dcn_fold_enabled() {   // GP_DCN_FOLD=0: A/B switch (fp16: mask weight folded into the corner weights)
-    static const bool on = [] { const char* e = getenv("GP_DCN_FOLD"); return !(e && e[0] == '0'); }();
+static bool dcn_fold_enabled() {   // GP_DCN_FOLD=1: measurement arm (fp16: mask weight folded into the corner weights; off by default, see MW in the kernel)
+    static const bool on = [] { const char* e = getenv("GP_DCN_FOLD"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -318,7 +320,7 @@ static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
 
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
     if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled()) {
-        if (sizeof(T) == 2 && !dcn_fold_enabled()) hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true, false>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
+        if (sizeof(T) == 2 && dcn_fold_enabled()) hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
     } else if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
