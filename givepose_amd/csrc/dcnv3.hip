@@ -303,6 +303,138 @@ __global__ __launch_bounds__(256) void dcnv3_wave_kernel(const DcnKP p) {
     st4(reinterpret_cast<T*>(p.out) + r * 256 + cl * 4, acc);
 }
 
+// ---------------------------------------------------------------------------- fp16, 3 x 3, SIXTEEN bytes per lane (round 6)
+// Why: a wave-level load instruction costs the CU's vector-memory path the same ~18 cycles at 8 and at 16 bytes per lane
+// (scripts/probes/gather_width.hip, profiles/r06_gather_width.txt: 28 against 50-57 B/clk/CU out of L1 / L2), and the kernel above -- 4 fp16 channels
+// = 8 bytes per lane, 36 loads per wave for 4 (pixel, group) pairs -- ran at exactly that rate whatever the offsets and the occupancy (80 us at 64 x 64,
+// offsets 0 .. 8 pixels, 3 .. 8 workgroups per CU: profiles/r06_dcn_wave8_ab.txt).  Here a lane owns EIGHT channels: a 16-lane row is one output
+// pixel x TWO groups (lanes 0-7 group 2 gp, lanes 8-15 group 2 gp + 1), a wave 4 pixels x 2 groups, so the same 36 loads serve 8 pairs.  Lanes t < 9
+// of a row own tap t of BOTH groups (the owner block of the kernel above, run once per group); the tap loop hands lanes 0-7 the first group's eight
+// numbers and lanes 8-15 the second's: two DPP row_share moves per number with bank masks 0x3 / 0xC.  Per channel the arithmetic and its order are
+// those of the kernel above: the outputs are bitwise the same (tests/test_hip_ops.py).
+typedef unsigned pk_u32x4 __attribute__((ext_vector_type(4)));
+// a * (fp16 half `hi` of u) in fp32 as ONE instruction: v_fma_mix_f32 with a zero addend reads the fp16 operand straight from its half of the packed register
+// (the compiler's cvt + mul are two).  The bits of the product, except that a zero product comes out as +0 -- which no sum downstream can tell
+// (the accumulators start at +0): checked bitwise against dcnv3_wave_kernel, where most corner weights of an edge pixel ARE zero.
+__device__ __forceinline__ float mul_mix(float a, unsigned u, int hi) {
+    float r;
+    if (hi) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(u));
+    else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(u));
+    return r;
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
+    const int lane = threadIdx.x & 63, t = lane & 15;
+    const int ppr = p.Wo >> 2, ppi = ppr * (p.Ho >> 2);
+    const int pid = p.xcd ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int b = pid / ppi, pin = pid - b * ppi;
+    const int ho = (pin / ppr) * 4 + (threadIdx.x >> 6), wo = (pin % ppr) * 4 + (lane >> 4);
+    const long r = ((long)b * p.Ho + ho) * p.Wo + wo;
+    const int halfk = (p.dil * 2) >> 1;
+    const float p0_w_ = (float)(halfk - p.pad + wo * p.stride) - halfk * p.os;
+    const float p0_h_ = (float)(halfk - p.pad + ho * p.stride) - halfk * p.os;
+    const float Hf = (float)p.H, Wf = (float)p.W;
+    const char* imb = reinterpret_cast<const char*>(reinterpret_cast<const half_t*>(p.in) + (long)__builtin_amdgcn_readfirstlane(b) * p.H * p.W * 256);
+    float w1[2], w2[2], w3[2], w4[2], mk[2];
+    unsigned o00[2], dx[2], dy[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // owner block (as dcnv3_wave_kernel), once per group of the pair
+        const int g = blockIdx.y * 2 + h;
+        float ow = 0.f, oh = 0.f, m = p.logits ? -INFINITY : 0.f;
+        if (t < 9) {
+            const OT* op = reinterpret_cast<const OT*>(p.off) + r * p.off_ld + (g * 9 + t) * 2;
+            ow = (float)op[0];
+            oh = (float)op[1];
+            m = (float)(reinterpret_cast<const OT*>(p.mask)[r * p.mask_ld + g * 9 + t]);
+        }
+        if (p.logits) {
+            const float mx = group_max(m, 16);
+            const float e = t < 9 ? expf(m - mx) : 0.f;
+            const float sm = group_sum(e, 16);
+            m = e / sm;
+        }
+        const int i = t / 3, j = t - i * 3;            // tap order: kernel_w outer, kernel_h inner
+        float loc_w = p0_w_ + (i * p.dil + ow) * p.os;
+        float loc_h = p0_h_ + (j * p.dil + oh) * p.os;
+        const bool in = t < 9 && loc_h > -1.f && loc_w > -1.f && loc_h < Hf && loc_w < Wf;
+        loc_w = in ? loc_w : 0.f;
+        loc_h = in ? loc_h : 0.f;
+        m = in ? m : 0.f;
+        const float fh = floorf(loc_h), fw = floorf(loc_w);
+        const float lh = loc_h - fh, lw = loc_w - fw, hh = 1.f - lh, hw = 1.f - lw;
+        const int h_low = (int)fh, w_low = (int)fw, h_high = h_low + 1, w_high = w_low + 1;
+        const bool hl = h_low >= 0, hhi = h_high <= p.H - 1, wl = w_low >= 0, whi = w_high <= p.W - 1;
+        w1[h] = (hl && wl) ? hh * hw : 0.f;
+        w2[h] = (hl && whi) ? hh * lw : 0.f;
+        w3[h] = (hhi && wl) ? lh * hw : 0.f;
+        w4[h] = (hhi && whi) ? lh * lw : 0.f;
+        mk[h] = m;
+        const int y0 = max(h_low, 0), y1 = min(h_high, p.H - 1), x0 = max(w_low, 0), x1 = min(w_high, p.W - 1);
+        o00[h] = (unsigned)((y0 * p.W + x0) * 256) * 2u;
+        dx[h] = (unsigned)((x1 - x0) * 256) * 2u;
+        dy[h] = (unsigned)((y1 - y0) * p.W * 256) * 2u;
+    }
+    const unsigned lo = (unsigned)(blockIdx.y * 128 + t * 8) * 2u;      // this lane's 8 channels inside a pixel (bytes)
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    // Software pipeline, spelled out: the four loads of tap q + 2 are issued before tap q is multiplied (12 loads = 12 KB per wave in flight), with
+    // scheduling barriers between the stages -- left alone, the compiler hoisted loads until it needed 159 registers (3 waves per SIMD: 77 us at 64 x 64
+    // against 57) and spilled when held to 128.
+    int a1 = 0, a2 = 0, a3 = 0, a4 = 0, wg = 0, bo = 0, ex = 0, ey = 0;          // broadcast destinations (kept across taps: no re-initialisation)
+    half8 v[3][4];
+    // lanes 0-7 of a row <- lane q's value for the first group (bank mask 0x3), lanes 8-15 <- lane q's value for the second (0xC); the first halves of a
+    // stage's numbers are issued together, then the second halves (a DPP move may not read a register the instruction before it wrote)
+#define GP_BCA(d, A, q) d = __builtin_amdgcn_update_dpp(d, __builtin_bit_cast(int, A), 0x150 + (q), 0xF, 0x3, false);
+#define GP_BCB(d, B, q) d = __builtin_amdgcn_update_dpp(d, __builtin_bit_cast(int, B), 0x150 + (q), 0xF, 0xC, false);
+    auto fetch = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        GP_BCA(bo, o00[0], q) GP_BCA(ex, dx[0], q) GP_BCA(ey, dy[0], q)
+        GP_BCB(bo, o00[1], q) GP_BCB(ex, dx[1], q) GP_BCB(ey, dy[1], q)
+        const unsigned b00 = (unsigned)bo + lo;
+        v[q % 3][0] = *reinterpret_cast<const half8*>(imb + (size_t)b00);
+        v[q % 3][1] = *reinterpret_cast<const half8*>(imb + (size_t)(b00 + (unsigned)ex));
+        v[q % 3][2] = *reinterpret_cast<const half8*>(imb + (size_t)(b00 + (unsigned)ey));
+        v[q % 3][3] = *reinterpret_cast<const half8*>(imb + (size_t)(b00 + (unsigned)ex + (unsigned)ey));
+    };
+    fetch(std::integral_constant<int, 0>{});
+    fetch(std::integral_constant<int, 1>{});
+    static_for<0, 9>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q + 2 < 9) fetch(std::integral_constant<int, q + 2>{});
+        asm volatile("" ::: "memory");             // (the loads of later taps stay behind this point: a scheduling barrier alone did not hold them)
+        __builtin_amdgcn_sched_barrier(0);
+        GP_BCA(a1, w1[0], q) GP_BCA(a2, w2[0], q) GP_BCA(a3, w3[0], q) GP_BCA(a4, w4[0], q) GP_BCA(wg, mk[0], q)
+        GP_BCB(a1, w1[1], q) GP_BCB(a2, w2[1], q) GP_BCB(a3, w3[1], q) GP_BCB(a4, w4[1], q) GP_BCB(wg, mk[1], q)
+        const float f1 = __builtin_bit_cast(float, a1), f2 = __builtin_bit_cast(float, a2), f3 = __builtin_bit_cast(float, a3),
+                    f4 = __builtin_bit_cast(float, a4), fg = __builtin_bit_cast(float, wg);
+        const half8 v1 = v[q % 3][0], v2 = v[q % 3][1], v3 = v[q % 3][2], v4 = v[q % 3][3];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float tt = mul_mix(f1, __builtin_bit_cast(pk_u32x4, v1)[c >> 1], c & 1);
+            tt = fmaf(f2, (float)v2[c], tt);
+            tt = fmaf(f3, (float)v3[c], tt);
+            tt = fmaf(f4, (float)v4[c], tt);
+            acc[c] = fmaf(tt, fg, acc[c]);
+        }
+        // (pins the tap's arithmetic here: the compiler otherwise sank the FMAs of taps 1 .. 8 behind the last load, with every loaded value live until then)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#undef GP_BCA
+#undef GP_BCB
+    half8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.out) + r * 256 + blockIdx.y * 128 + t * 8) = o;
+}
+
+static bool dcn_wave8_enabled() {   // GP_DCN_WAVE8=0: A/B switch, read per call (tests flip it inside one process): the 8-bytes-per-lane kernel
+    const char* e = getenv("GP_DCN_WAVE8");
+    return !(e && e[0] == '0');
+}
+
 static bool dcn_xcd_enabled() {   // GP_DCN_XCD=0: A/B switch for the XCD-contiguous workgroup order
     static const bool on = [] { const char* e = getenv("GP_DCN_XCD"); return !(e && e[0] == '0'); }();
     return on;
@@ -313,15 +445,26 @@ static bool dcn_fold_enabled() {   // GP_DCN_FOLD=1: measurement arm (fp16: mask
     return on;
 }
 
+static int dcn_lds_pad() {   // GP_DCN_LDS_PAD=<bytes>: unused dynamic LDS per workgroup = fewer workgroups per CU (experiment: L1 footprint)
+    static const int k = [] { const char* e = getenv("GP_DCN_LDS_PAD"); return e ? atoi(e) : 0; }();
+    return k;
+}
+
 static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
     static const bool on = [] { const char* e = getenv("GP_DCN_PATCH"); return !(e && e[0] == '0'); }();
     return on;
 }
 
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled() && dcn_wave8_enabled() && !dcn_fold_enabled()) {
+            hipLaunchKernelGGL((dcnv3_wave8_kernel<OT>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 2), dim3(256), 0, s, p);
+            return 0;
+        }
+    }
     if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled()) {
         if (sizeof(T) == 2 && dcn_fold_enabled()) hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 4), dim3(256), dcn_lds_pad(), s, p);
     } else if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc) {
         hipLaunchKernelGGL((dcnv3_wave_kernel<T, OT, 3>), dim3(cdiv(p.rows, 4)), dim3(256), 0, s, p);
     } else if (p.G == 4 && p.D == 64 && p.K * p.K - p.rc <= 16) {

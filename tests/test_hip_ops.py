@@ -629,6 +629,38 @@ def test_dcnv3_fused_softmax_and_strided_om():
     assert ref.shape == (N, Ho, Ho, 256)
 
 
+@pytest.mark.parametrize("N,H,off_scale,logits,om32", [(5, 16, 1.5, True, True), (3, 32, 4.0, True, True), (2, 64, 0.0, True, True), (4, 16, 12.0, False, False), (1, 8, 2.0, False, True)])
+def test_dcnv3_sixteen_bytes_per_lane_kernel_is_bitwise_the_eight_byte_one(N, H, off_scale, logits, om32):
+    """dcnv3_wave8_kernel (round 6: 8 fp16 channels per lane, a 16-lane row = one pixel x TWO groups) against dcnv3_wave_kernel (4 channels per lane,
+    GP_DCN_WAVE8=0 -- the switch is read per call): same per-channel arithmetic in the same order, so the outputs are the same bits; against the oracle as
+    well.  Offsets from 0 (every tap on the grid) to 12 pixels (most taps outside the map: zero corners, clamped addresses); masks as logits (softmax in
+    the kernel) and as weights; fp32 and fp16 offset / mask rows; 8 x 8 .. 64 x 64 maps (stride 2: output 4 x 4 .. 32 x 32)."""
+    from oracle.posenet_ref import dcnv3_forward_ref
+    o = ops()
+    G, D, K, P = 4, 64, 3, 9
+    Ho = H // 2
+    x = q(rnd(N, H, H, 256, seed=230), torch.float16)
+    om = rnd(N * Ho * Ho, 108, seed=231, scale=1.0)
+    om[:, :72] *= off_scale
+    if not logits:
+        om[:, 72:] = torch.softmax(om[:, 72:].reshape(-1, G, P), -1).reshape(-1, G * P)
+    omd = om.cuda() if om32 else q(om, torch.float16).cuda().half()
+    outs = {}
+    for arm in ("0", "1"):
+        os.environ["GP_DCN_WAVE8"] = arm
+        try:
+            out = torch.full((N, Ho, Ho, 256), float("nan"), dtype=torch.float16, device="cuda")
+            o.dcnv3_forward_into(x.cuda().half(), omd, omd[:, 72:], out, K, 2, 1, 1, G, D, 1.0, off_ld=108, mask_ld=108, mask_is_logits=logits)
+            outs[arm] = out
+        finally:
+            os.environ.pop("GP_DCN_WAVE8", None)
+    assert torch.equal(outs["0"], outs["1"]), float((outs["0"].float() - outs["1"].float()).abs().max())
+    omr = omd.float().cpu()
+    mask = torch.softmax(omr[:, 72:].reshape(-1, G, P), -1).reshape(-1, G * P) if logits else omr[:, 72:]
+    ref = dcnv3_forward_ref(x, omr[:, :72].contiguous(), mask.contiguous(), K, 2, 1, 1, G, D, 1.0, 0)
+    assert rel_err(outs["1"], ref) < 2e-3
+
+
 def test_dcnv3_generic_geometry_and_errors():
     from oracle.posenet_ref import dcnv3_forward_ref
     from givepose_amd._lib import GivePoseHipError
