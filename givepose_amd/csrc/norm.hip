@@ -211,6 +211,104 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------- dw3x3 + LN (+GELU), LDS-tiled (round 6)
+// The DCNv3 prefix kernel (ops_dcnv3/modules/dcnv3.py:318-356: x1 = GELU(LN(dw3x3(x))), C = 256) ran on the strip kernel above at 2.7-3.4 x its HBM floor
+// (64 x 64 prefix of 64 crops: 28.9 us for 67 MB, profiles/r06_dw3_forms.txt): every thread fetched its own 3 x 4 input window and its nine taps from L1 / L2,
+// row by row.  Here a workgroup owns 16 x 4 output pixels x all 256 channels: the 18 x 6 halo window (54 KB; out-of-image pixels are zeros) goes through LDS
+// once, a thread (channel octet o = t % 32, pixel slot t / 32: row slot / 2, column half slot % 2) convolves 8 neighbouring pixels of one row from 10 LDS
+// vectors per filter row.  Arithmetic, its order, the two-pass LayerNorm (group_sum over the pixel's 32 lanes) and the GELU are the strip kernel's: same bits.
+// Only whole 4-row blocks of the flat (image, row) list (the prefix of a batch whose crop count is a multiple of 4 is whole images; otherwise the host checks).
+// GELU only (the DCNv3 prefix kernel's activation, compiled in: the strip kernel's per-element `act` switch costs a scalar branch per value -- 2 896 -> 2 210
+// vector instructions per thread; without an activation the compiler contracts the LayerNorm's last multiply-add differently in the two kernels (1 ulp), so
+// that case stays on the strip kernel)
+template <int TH>      // tile height: 4 (8 pixels per thread, 54 KB of LDS: two workgroups per CU) or 2 (4 pixels per thread, 36 KB: four)
+__global__ __launch_bounds__(256) void dwconv3_ln_tile_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt, const float* __restrict__ bias,
+                                                              const float* __restrict__ lnw, const float* __restrict__ lnb, half_t* __restrict__ y,
+                                                              int H, int W, float eps) {
+    constexpr int C = 256, HR = TH + 2, HC = 18, PPT = 2 * TH, SPR = 16 / PPT;      // pixels per thread, pixel slots per tile row
+    extern __shared__ __attribute__((aligned(16))) char dw3_lds[];      // [HR][HC][C] halfs = 55 296 bytes
+    const int t = threadIdx.x, o = t & 31, slot = t >> 5, r = slot / SPR, ch = slot % SPR;
+    const int tpr = W >> 4;
+    const int rb = blockIdx.x / tpr, c0 = (blockIdx.x - rb * tpr) * 16;
+    const long row0 = (long)rb * TH;                // first row of the block in the flat (image, row) list
+    const int h0 = (int)(row0 % H);
+    const half_t* xim = x + (row0 - h0) * W * C;    // pixel (0, 0) of the block's image
+    // ---- halo window -> LDS: piece i = (halo pixel i / 32, octet i % 32); 32 neighbouring lanes fetch one pixel's 512 contiguous bytes
+    constexpr int NPC = HR * HC * 32, NIT = (NPC + 255) / 256;
+    uint4 pc[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = t + 256 * k, px = i >> 5, hr = px / HC, hc = px - hr * HC;
+        const int hi = h0 - 1 + hr, wi = c0 - 1 + hc;
+        pc[k] = (i < NPC && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    ? *reinterpret_cast<const uint4*>(xim + ((long)hi * W + wi) * C + (i & 31) * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+    Vec16<half_t> wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = load16<half_t>(wt + k * C + o * 8);
+    float acc[PPT][8];
+    {
+        float bv[8];
+        load_f32<half_t>(bias + o * 8, bv);
+#pragma unroll
+        for (int p = 0; p < PPT; ++p)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[p][e] = bv[e];
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = t + 256 * k;
+        if (i < NPC) *reinterpret_cast<uint4*>(dw3_lds + (size_t)i * 16) = pc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        Vec16<half_t> in[PPT + 2];
+#pragma unroll
+        for (int j = 0; j < PPT + 2; ++j) in[j].u = *reinterpret_cast<const uint4*>(dw3_lds + (size_t)(((r + kh) * HC + ch * PPT + j) * 32 + o) * 16);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) mac16<half_t>(acc[p], in[p + kw], wv[kh * 3 + kw]);
+    }
+    // ---- LayerNorm over the pixel's 256 channels = its 32 lanes (two-pass, as the strip kernel), activation, store
+    float sm[PPT], vr[PPT];
+    const float invC = 1.0f / C;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += acc[p][e];
+        sm[p] = group_sum(a, 32);
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const float mean = sm[p] * invC;
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[p][e] -= mean;
+            a += acc[p][e] * acc[p][e];
+        }
+        vr[p] = group_sum(a, 32);
+    }
+    float gw[8], gb[8];
+    load_f32<half_t>(lnw + o * 8, gw);
+    load_f32<half_t>(lnb + o * 8, gb);
+    half_t* yb = y + ((row0 + r) * W + c0 + ch * PPT) * C + o * 8;
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const float rstd = rsqrtf(vr[p] * invC + eps);
+        Vec16<half_t> ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float val = acc[p][e] * rstd * gw[e] + gb[e];
+            ov.set(e, gelu_for<half_t>(val));
+        }
+        store16<half_t>(yb + (long)p * C, ov);
+    }
+}
+
 // ---------------------------------------------------------------------------- dw7x7 + LN, LDS-tiled
 // The strip kernel above re-reads every input row 7x and every filter tap once per 8 pixels from L1/L2 and is
 // bound by L2->L1 traffic (12x read amplification, profiles/r01a).  Here a workgroup owns a TW x TH output tile
@@ -1692,6 +1790,18 @@ __global__ __launch_bounds__(256) void gn_upsample2x_kernel(const half_t* __rest
 
 }  // namespace
 
+static int dw3_tile_rows() {   // GP_DW3_TILE_ROWS=4|2: rows of a dwconv3_ln_tile_kernel tile (A/B)
+    static const int k = [] { const char* e = getenv("GP_DW3_TILE_ROWS"); return e && atoi(e) == 4 ? 4 : 2; }();
+    return k;
+}
+static long dw3_tile_min() {   // fewest 16 x 4 tiles that go to dwconv3_ln_tile_kernel (GP_DW3_TILE_MIN: A/B; a huge value switches it off)
+    static const long k = [] { const char* e = getenv("GP_DW3_TILE_MIN"); return e ? atol(e) : 256l; }();
+    return k;
+}
+static bool dw3_narrow_always() {   // GP_DW3_NARROW=0: the 3 x 3 strip kernel back on 8 pixels per thread above dw_narrow_below() workgroups (A/B)
+    static const bool on = [] { const char* e = getenv("GP_DW3_NARROW"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static long dw_narrow_below() {   // strip kernel: 2 pixels per thread when 8 would give fewer workgroups than this (GP_DW_NARROW_BELOW: A/B)
     static const long k = [] { const char* e = getenv("GP_DW_NARROW_BELOW"); return e ? atol(e) : 128l; }();
     return k;
@@ -1816,8 +1926,31 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
         }
         if (done) GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
+    // KS = 3 (the DCNv3 prefix kernel), fp16, C = 256, whole 4-row blocks of 16-pixel-wide column tiles: the LDS-tiled kernel from dw3_tile_min() tiles up
+    // (act code 120 + act forces it: tests)
+    {
+        const int dbg3 = dbg >= 20 && dbg < 30 ? 1 : 0;      // (act codes >= 100 were turned into dbg = code - 100 above)
+        const int act3 = dbg3 ? dbg - 20 : act;
+        const int th3 = dbg3 ? (dbg >= 25 ? 2 : 4) : dw3_tile_rows();      // (act codes 120 + act: the 4-row tile, 125 + act: the 2-row tile)
+        const int act3b = dbg3 && dbg >= 25 ? dbg - 25 : act3;
+        if (KS == 3 && dtype == GP_F16 && C == 256 && pl == 0 && act3b == GP_ACT_GELU && H % th3 == 0 && W % 16 == 0 && n_pixels % ((long)th3 * W) == 0 &&
+            x != y && (dbg3 || n_pixels / 64 >= dw3_tile_min())) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)dwconv3_ln_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 18 * 512);
+                (void)hipFuncSetAttribute((const void*)dwconv3_ln_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 18 * 512);
+                attr_set = true;
+            }
+            if (th3 == 4) hipLaunchKernelGGL(dwconv3_ln_tile_kernel<4>, dim3((unsigned)(n_pixels / 64)), dim3(256), 6 * 18 * 512, s, (const half_t*)x, (const half_t*)wt, bias, ln_w, ln_b, (half_t*)y, H, W, eps);
+            else hipLaunchKernelGGL(dwconv3_ln_tile_kernel<2>, dim3((unsigned)(n_pixels / 32)), dim3(256), 4 * 18 * 512, s, (const half_t*)x, (const half_t*)wt, bias, ln_w, ln_b, (half_t*)y, H, W, eps);
+            GP_LAUNCH_CHECK("gp_dwconv_ln");
+        }
+        GP_REQUIRE(!dbg3, "gp_dwconv_ln: act code 12x (forced 3 x 3 tile kernel) on a shape it does not take");
+    }
     // few pixels (fewer than one 8-pixel-strip workgroup per two CUs): 2 pixels per thread, four times the workgroups
-    const bool narrow = dtype == GP_F16 && cdiv(strips, PG) < dw_narrow_below();
+    // (KS = 3, the DCNv3 prefix kernel: the 2-pixel form with its rolling prefetch wins at every size -- 64 x 64 / 32 x 32 prefix of 64 crops 36.6 / 15.2 -> 28.9 / 10.1 us,
+    // 128 crops 62 -> 53: profiles/r06_dw3_forms.txt; GP_DW3_NARROW=0: A/B switch)
+    const bool narrow = dtype == GP_F16 && (cdiv(strips, PG) < dw_narrow_below() || (KS == 3 && dw3_narrow_always()));
     dim3 grid(narrow ? cdiv((n_pixels + 1) / 2, PG) : cdiv(strips, PG));
 #define GP_DW(T, K, P) hipLaunchKernelGGL((dwconv_ln_kernel<T, K, P>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, pl)
     if (dtype == GP_F16) {
@@ -1844,7 +1977,7 @@ extern "C" int gp_dwconv_ln_groups(const void* x, const void* wt, const float* b
     hipStream_t s = (hipStream_t)stream;
     gp_timing_before(s, GP_KC_DWCONV_LN, 2.0 * n_pixels * C * KS * KS, (double)n_pixels * C * esz * 2);
     gp_timing_label("dwconv%d_ln groups C%d %dx%d B%d", KS, C, H, W, B);
-    const bool narrow = dtype == GP_F16 && cdiv(strips, PG) < dw_narrow_below();
+    const bool narrow = dtype == GP_F16 && (cdiv(strips, PG) < dw_narrow_below() || (KS == 3 && dw3_narrow_always()));
     dim3 grid(narrow ? cdiv((n_pixels + 1) / 2, PG) : cdiv(strips, PG));
 #define GP_DWG(T, K, P) hipLaunchKernelGGL((dwconv_ln_kernel<T, K, P>), grid, dim3(256), 0, s, (const T*)x, (const T*)wt, bias, ln_w, ln_b, (T*)y, H, W, C, eps, act, n_pixels, 0l, crop_group_start)
     if (dtype == GP_F16) {

@@ -743,6 +743,41 @@ def test_dwconv_ln_fp16_kernels_by_grid_size(C, H, KS, B, offset):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,H,W,gelu", [(8, 16, 16, True), (4, 32, 32, True), (6, 32, 32, True), (1, 64, 64, True), (4, 32, 16, True), (16, 64, 64, True), (3, 16, 48, True)])
+def test_dwconv3_ln_tile_kernel_is_bitwise_the_strip_kernel(B, H, W, gelu):
+    """dwconv3_ln_tile_kernel (round 6: the DCNv3 prefix kernel dw3x3 -> LN -> GELU with its 18 x 6 halo window in LDS; act code 120 + act forces it) against the
+    strip kernel on the same prefix (the first quarter of the flat pixel rows, ops_dcnv3/modules/dcnv3.py:318-356 + SURVEY 0.3): same arithmetic in the same
+    order, so the same bits; and against the fp32 reference.  Prefixes that are whole images (B % 4 == 0), that end inside an image (B = 6: 1.5 images; B = 1 and
+    3: a quarter / three quarters of one -- the halo row below the prefix is real data), a non-square map, W = 48 (three column tiles).  GELU only: without an
+    activation the launch stays on the strip kernel (forcing the tile kernel is refused)."""
+    o = ops()
+    C, dt = 256, torch.float16
+    x = q(rnd(B, C, H, W, seed=240), dt)
+    w, b = q(rnd(C, 1, 3, 3, seed=241, scale=1.0 / 3), dt), rnd(C, seed=242, scale=0.1)
+    lw, lb = 1 + 0.1 * rnd(C, seed=243), 0.1 * rnd(C, seed=244)
+    n = B * H * W // 4
+    ref = F.layer_norm(F.conv2d(x, w, b, padding=1, groups=C).permute(0, 2, 3, 1), (C,), lw, lb, 1e-6)
+    if gelu:
+        ref = F.gelu(ref)
+    ref = ref.reshape(-1, C)[:n]
+    xd = x.permute(0, 2, 3, 1).contiguous().to("cuda", dt)
+    wd = w.reshape(C, 9).t().contiguous().to("cuda", dt)
+    act = o.ACT_GELU if gelu else o.ACT_NONE
+    tile = torch.full((n, C), float("nan"), dtype=dt, device="cuda")
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), tile, 3, act=120 + act, n_pixels=n)       # 16 x 4 tiles
+    assert rel_err(tile, ref) < TOL[dt], rel_err(tile, ref)
+    tile2 = torch.full((n, C), float("nan"), dtype=dt, device="cuda")
+    o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), tile2, 3, act=125 + act, n_pixels=n)      # 16 x 2 tiles (the routed form)
+    assert torch.equal(tile, tile2)
+    from givepose_amd._lib import GivePoseHipError
+    with pytest.raises(GivePoseHipError):
+        o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), torch.empty_like(tile), 3, act=120 + o.ACT_NONE, n_pixels=n)
+    if n // 64 < 256:                      # below 256 tiles the routing itself takes the strip kernel
+        strip = torch.full((n, C), float("nan"), dtype=dt, device="cuda")
+        o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), strip, 3, act=act, n_pixels=n)
+        assert torch.equal(tile, strip), float((tile.float() - strip.float()).abs().max())
+
+
 @pytest.mark.parametrize("C,H,B,offset,W", [(512, 16, 3, 0.0, 16), (512, 16, 128, 0.0, 16), (256, 16, 5, 0.0, 16), (128, 16, 2, 0.0, 16), (512, 8, 2, 0.0, 16),
                                             (512, 32, 2, 0.0, 16), (256, 24, 1, 0.0, 16), (512, 16, 7, 5.0, 16),
                                             (128, 64, 2, 0.0, 64), (256, 32, 3, 0.0, 32), (128, 24, 1, 0.0, 48), (256, 8, 2, 0.0, 32), (128, 64, 1, 5.0, 64),
