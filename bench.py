@@ -518,7 +518,7 @@ def main():
                                            "frac_of_bare_mfma_loop": round(g["tflops"] / 1830.0, 3)} if args.dtype != "f32" else None}
         if "dcnv3" in classes:
             d = classes["dcnv3"]
-            line["roofline_gather"] = {"kernel": "dcnv3_wave_kernel", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
+            line["roofline_gather"] = {"kernel": "dcnv3_wave8_kernel (fp16; dcnv3_wave_kernel in the fp32 modes)", "bound": "hbm", "achieved": d["gbs"], "peak": PEAK_HBM_GBS,
                                        "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None,
                                        "alg_bytes_per_launch": d["alg_bytes_per_launch"]}
         # HBM traffic of the same kernel classes from PMC counters (rocprofv3 --pmc passes, FETCH_SIZE/WRITE_SIZE corrected as
