@@ -110,16 +110,29 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         gw[nt] = *reinterpret_cast<const f32x4*>(lnw + n);
         gb[nt] = *reinterpret_cast<const f32x4*>(lnb + n);
     }
+    // the patch rows of output row hr + 1 are fetched into registers while row hr is multiplied and normalised (three 16-byte pieces per thread):
+    // a workgroup's rows used to be load -> wait -> compute one after the other
+    f32x4 nxt[3];
+    auto fetch_row = [&](int hr) {
+        const int ho = hog * RPW + hr;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {              // 12 (c, kh) rows x 64 16-byte pieces
+            const int i = tid + 256 * k, row = i >> 6, c4 = i & 63;
+            const int c = row >> 2, kh = row & 3;
+            nxt[k] = *reinterpret_cast<const f32x4*>(img + (((long)b * 3 + c) * H + (ho * 4 + kh)) * W + wo0 * 4 + c4 * 4);
+        }
+    };
+    fetch_row(0);
     for (int hr = 0; hr < RPW; ++hr) {
     const int ho = hog * RPW + hr;
     if (hr) __syncthreads();                       // every wave is done with the previous row's patch and statistics
-    for (int i = tid; i < 12 * 64; i += 256) {     // 12 (c, kh) rows x 64 16-byte pieces
-        const int row = i >> 6, c4 = i & 63;
-        const int c = row >> 2, kh = row & 3;
-        *reinterpret_cast<f32x4*>(&in_s[row][c4 * 4]) =
-            *reinterpret_cast<const f32x4*>(img + (((long)b * 3 + c) * H + (ho * 4 + kh)) * W + wo0 * 4 + c4 * 4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = tid + 256 * k;
+        *reinterpret_cast<f32x4*>(&in_s[i >> 6][(i & 63) * 4]) = nxt[k];
     }
     __syncthreads();
+    if (hr + 1 < RPW) fetch_row(hr + 1);
     f32x4 acc[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
