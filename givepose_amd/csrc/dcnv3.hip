@@ -323,9 +323,15 @@ __device__ __forceinline__ float mul_mix(float a, unsigned u, int hi) {
     return r;
 }
 
-template <typename OT>
+// LB (measurement arm, GP_DCN_LDSBC=1): the eight numbers of a (pixel, group, tap) go from their owner lane to the 8 lanes that need them through LDS (two 16-byte
+// broadcast reads per tap, issued a stage ahead) instead of 16 bank-masked DPP moves per tap: 771 -> ~640 vector instructions per wave, same bits -- and the same
+// 52 us at 64 x 64 (profiles/r06_dcn_wave8_ab.txt [5]): with 16-byte loads the kernel sits on its load instructions again (36 per wave x ~18 cycles = 35 us at 2.4 GHz),
+// not on vector issue.  Not the default.
+template <typename OT, bool LB>
 __global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
+    __shared__ __attribute__((aligned(16))) uint4 bc_s[LB ? 4 * 72 * 2 : 1];       // [wave][(pixel row of the wave, group of the pair, tap)][weights | mask, offsets]
     const int lane = threadIdx.x & 63, t = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ppr = p.Wo >> 2, ppi = ppr * (p.Ho >> 2);
     const int pid = p.xcd ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
     const int b = pid / ppi, pin = pid - b * ppi;
@@ -374,7 +380,16 @@ __global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
         o00[h] = (unsigned)((y0 * p.W + x0) * 256) * 2u;
         dx[h] = (unsigned)((x1 - x0) * 256) * 2u;
         dy[h] = (unsigned)((y1 - y0) * p.W * 256) * 2u;
+        if constexpr (LB) {
+            if (t < 9) {
+                uint4* rec = bc_s + ((wave * 72 + ((lane >> 4) * 2 + h) * 9 + t) * 2);
+                rec[0] = uint4{__builtin_bit_cast(unsigned, w1[h]), __builtin_bit_cast(unsigned, w2[h]), __builtin_bit_cast(unsigned, w3[h]), __builtin_bit_cast(unsigned, w4[h])};
+                rec[1] = uint4{__builtin_bit_cast(unsigned, m), o00[h], dx[h], dy[h]};
+            }
+        }
     }
+    if constexpr (LB) __builtin_amdgcn_wave_barrier();      // (a wave's LDS instructions execute in order: the reads below see these writes; this only pins the compiler's order)
+    const uint4* myrec = bc_s + (wave * 72 + ((lane >> 4) * 2 + (t >> 3)) * 9) * 2;
     const unsigned lo = (unsigned)(blockIdx.y * 128 + t * 8) * 2u;      // this lane's 8 channels inside a pixel (bytes)
     float acc[8];
 #pragma unroll
@@ -384,14 +399,23 @@ __global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
     // against 57) and spilled when held to 128.
     int a1 = 0, a2 = 0, a3 = 0, a4 = 0, wg = 0, bo = 0, ex = 0, ey = 0;          // broadcast destinations (kept across taps: no re-initialisation)
     half8 v[3][4];
+    uint4 ra[3];          // LB: the four corner weights of the stage's tap
+    unsigned rg[3];       // LB: its mask weight
     // lanes 0-7 of a row <- lane q's value for the first group (bank mask 0x3), lanes 8-15 <- lane q's value for the second (0xC); the first halves of a
     // stage's numbers are issued together, then the second halves (a DPP move may not read a register the instruction before it wrote)
 #define GP_BCA(d, A, q) d = __builtin_amdgcn_update_dpp(d, __builtin_bit_cast(int, A), 0x150 + (q), 0xF, 0x3, false);
 #define GP_BCB(d, B, q) d = __builtin_amdgcn_update_dpp(d, __builtin_bit_cast(int, B), 0x150 + (q), 0xF, 0xC, false);
     auto fetch = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
+        if constexpr (LB) {
+            const uint4 rb = myrec[q * 2 + 1];
+            ra[q % 3] = myrec[q * 2];
+            rg[q % 3] = rb.x;
+            bo = (int)rb.y; ex = (int)rb.z; ey = (int)rb.w;
+        } else {
         GP_BCA(bo, o00[0], q) GP_BCA(ex, dx[0], q) GP_BCA(ey, dy[0], q)
         GP_BCB(bo, o00[1], q) GP_BCB(ex, dx[1], q) GP_BCB(ey, dy[1], q)
+        }
         const unsigned b00 = (unsigned)bo + lo;
         v[q % 3][0] = *reinterpret_cast<const half8*>(imb + (size_t)b00);
         v[q % 3][1] = *reinterpret_cast<const half8*>(imb + (size_t)(b00 + (unsigned)ex));
@@ -405,8 +429,12 @@ __global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
         if constexpr (q + 2 < 9) fetch(std::integral_constant<int, q + 2>{});
         asm volatile("" ::: "memory");             // (the loads of later taps stay behind this point: a scheduling barrier alone did not hold them)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LB) {
+            a1 = (int)ra[q % 3].x; a2 = (int)ra[q % 3].y; a3 = (int)ra[q % 3].z; a4 = (int)ra[q % 3].w; wg = (int)rg[q % 3];
+        } else {
         GP_BCA(a1, w1[0], q) GP_BCA(a2, w2[0], q) GP_BCA(a3, w3[0], q) GP_BCA(a4, w4[0], q) GP_BCA(wg, mk[0], q)
         GP_BCB(a1, w1[1], q) GP_BCB(a2, w2[1], q) GP_BCB(a3, w3[1], q) GP_BCB(a4, w4[1], q) GP_BCB(wg, mk[1], q)
+        }
         const float f1 = __builtin_bit_cast(float, a1), f2 = __builtin_bit_cast(float, a2), f3 = __builtin_bit_cast(float, a3),
                     f4 = __builtin_bit_cast(float, a4), fg = __builtin_bit_cast(float, wg);
         const half8 v1 = v[q % 3][0], v2 = v[q % 3][1], v3 = v[q % 3][2], v4 = v[q % 3][3];
@@ -428,6 +456,11 @@ __global__ __launch_bounds__(256) void dcnv3_wave8_kernel(const DcnKP p) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[c];
     *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(p.out) + r * 256 + blockIdx.y * 128 + t * 8) = o;
+}
+
+static bool dcn_ldsbc_enabled() {   // GP_DCN_LDSBC=1: measurement arm, read per call: dcnv3_wave8_kernel with LDS records instead of the DPP broadcasts
+    const char* e = getenv("GP_DCN_LDSBC");
+    return e && e[0] == '1';
 }
 
 static bool dcn_wave8_enabled() {   // GP_DCN_WAVE8=0: A/B switch, read per call (tests flip it inside one process): the 8-bytes-per-lane kernel
@@ -458,7 +491,8 @@ static bool dcn_patch_enabled() {   // GP_DCN_PATCH=0: A/B switch
 template <typename T, typename OT> int launch(const DcnKP& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         if (p.G == 4 && p.D == 64 && p.K == 3 && !p.rc && p.Ho % 4 == 0 && p.Wo % 4 == 0 && dcn_patch_enabled() && dcn_wave8_enabled() && !dcn_fold_enabled()) {
-            hipLaunchKernelGGL((dcnv3_wave8_kernel<OT>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 2), dim3(256), 0, s, p);
+            if (dcn_ldsbc_enabled()) hipLaunchKernelGGL((dcnv3_wave8_kernel<OT, true>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 2), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((dcnv3_wave8_kernel<OT, false>), dim3(p.N * (p.Ho / 4) * (p.Wo / 4), 2), dim3(256), 0, s, p);
             return 0;
         }
     }

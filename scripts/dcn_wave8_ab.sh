@@ -4,5 +4,6 @@
 N=${1:-3}
 for i in $(seq 1 $N); do
   echo "pair $i arm A (GP_DCN_WAVE8=0: 8 bytes per lane)"; GP_DCN_WAVE8=0 python3 scripts/dcn_bench.py 2>/dev/null
-  echo "pair $i arm B (default: 16 bytes per lane)"; python3 scripts/dcn_bench.py 2>/dev/null
+  echo "pair $i arm B (default: 16 bytes per lane, DPP broadcasts)"; python3 scripts/dcn_bench.py 2>/dev/null
+  echo "pair $i arm C (GP_DCN_LDSBC=1: 16 bytes per lane, LDS records)"; GP_DCN_LDSBC=1 python3 scripts/dcn_bench.py 2>/dev/null
 done

@@ -646,15 +646,17 @@ def test_dcnv3_sixteen_bytes_per_lane_kernel_is_bitwise_the_eight_byte_one(N, H,
         om[:, 72:] = torch.softmax(om[:, 72:].reshape(-1, G, P), -1).reshape(-1, G * P)
     omd = om.cuda() if om32 else q(om, torch.float16).cuda().half()
     outs = {}
-    for arm in ("0", "1"):
-        os.environ["GP_DCN_WAVE8"] = arm
+    for arm, env in (("0", {"GP_DCN_WAVE8": "0"}), ("dpp", {"GP_DCN_LDSBC": "1"}), ("1", {})):     # 8 bytes per lane | 16 bytes, LDS records (measurement arm) | 16 bytes, DPP broadcasts (the default)
+        os.environ.update(env)
         try:
             out = torch.full((N, Ho, Ho, 256), float("nan"), dtype=torch.float16, device="cuda")
             o.dcnv3_forward_into(x.cuda().half(), omd, omd[:, 72:], out, K, 2, 1, 1, G, D, 1.0, off_ld=108, mask_ld=108, mask_is_logits=logits)
             outs[arm] = out
         finally:
-            os.environ.pop("GP_DCN_WAVE8", None)
+            for k in env:
+                os.environ.pop(k, None)
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"].float() - outs["1"].float()).abs().max())
+    assert torch.equal(outs["dpp"], outs["1"]), float((outs["dpp"].float() - outs["1"].float()).abs().max())
     omr = omd.float().cpu()
     mask = torch.softmax(omr[:, 72:].reshape(-1, G, P), -1).reshape(-1, G * P) if logits else omr[:, 72:]
     ref = dcnv3_forward_ref(x, omr[:, :72].contiguous(), mask.contiguous(), K, 2, 1, 1, G, D, 1.0, 0)
