@@ -47,6 +47,47 @@ __global__ __launch_bounds__(256) void gather(const char* __restrict__ buf, unsi
     if (acc == 123.456f) out[0] = acc;
 }
 
+// LDS-DMA arm: the same gathered 1 KB per instruction (8 lanes x 16 bytes per 128-byte segment), written straight into LDS (global_load_lds_dwordx4)
+__global__ __launch_bounds__(256) void gather_dma(const char* __restrict__ buf, unsigned ws_mask, int iters, float* out) {
+    __shared__ __attribute__((aligned(1024))) char lds[4 * 4 * 1024];          // 4 waves x 4 KB
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    const int lane = threadIdx.x & 63, seg = lane / 8, within = lane % 8;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned wid = blockIdx.x * 4 + wave;
+    unsigned state = wid * 2654435761u + seg * 40503u + 12345u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_t*)lds + wave * 4096);
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            state = state * 1664525u + 1013904223u;
+            const unsigned off = ((state >> 4) & ws_mask & ~127u) + within * 16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(buf), "s"(lds0 + u * 1024) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (reinterpret_cast<float*>(lds)[threadIdx.x] == 123.456f) out[0] = 1.f;
+}
+
+int run_dma(const char* buf, size_t ws, float* out, hipStream_t s) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int G = 256 * 8, iters = 512;
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(gather_dma, dim3(G), dim3(256), 0, s, buf, (unsigned)(ws - 1), iters, out);
+        CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double instr = (double)G * 4 * iters, bytes = instr * 1024;
+    printf("  16 B per lane, LDS-DMA (global_load_lds_dwordx4): %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz)  %5.2f ns per wave-load per CU\n", best * 1e3, bytes / best / 1e9,
+           bytes / 256 / (best * 1e-3 * 2.4e9), best * 1e6 / (instr / 256));
+    return 0;
+}
+
 template <int BPL> int run(const char* buf, size_t ws, float* out, hipStream_t s) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int G = 256 * 8, iters = 512;          // 8 workgroups of 4 waves per CU
@@ -71,7 +112,7 @@ int main() {
     hipStream_t s; CK(hipStreamCreate(&s));
     for (size_t ws : {16384ull, 1ull << 20, 512ull << 20}) {
         printf("working set %zu KB\n", ws >> 10);
-        if (run<4>(buf, ws, out, s) || run<8>(buf, ws, out, s) || run<16>(buf, ws, out, s)) return 1;
+        if (run<4>(buf, ws, out, s) || run<8>(buf, ws, out, s) || run<16>(buf, ws, out, s) || run_dma(buf, ws, out, s)) return 1;
     }
     return 0;
 }
