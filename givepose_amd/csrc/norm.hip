@@ -865,8 +865,9 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
                                                                  const float* __restrict__ bias, const float* __restrict__ lnw,
                                                                  const float* __restrict__ lnb, half_t* __restrict__ y, int H, int Wrt, float eps) {
     constexpr int C = 64 * NS, NP = TH / 2, IH = TH + 6, PITCH = WIDE ? 22 : 18, ROWB = PITCH * 128, NPX = 16 * TH, NBF = NP + 2;
-    static_assert(TH == 8 || (TH == 4 && !WIDE), "tile height");
-    static_assert(!PAIR || (!WIDE && TH == 4), "pair tiles: 8-wide maps, quarter... half-image tiles of two images");
+    static_assert(TH == 8 || (TH == 4 && !WIDE) || (TH == 2 && PAIR), "tile height");
+    static_assert(!PAIR || (!WIDE && (TH == 4 || TH == 2)), "pair tiles: 8-wide maps, half- or quarter-image tiles of two images");
+    constexpr int NHF = NP >= 2 ? 2 : 1, PPH = NP / NHF;       // halves of the staging epilogue, row pairs per half
     constexpr int IN_BYTES = (IH * ROWB + 1023) / 1024 * 1024, TAP_OFF = IN_BYTES, PAD_OFF = TAP_OFF + 7 * 1024, STAGE = PAD_OFF + 1024;   // PAD_OFF: 1 KB, target of the padding DMA instructions
     // WIDE: ONE stage and two workgroups per CU (<= 128 registers, 57-59 KB of LDS each): a map of 64 x 64 is many rounds of tiles, so it is another
     // workgroup's conv that covers this one's prologue, slab latency and epilogue, not a ring inside the workgroup (measured: one workgroup per CU with a
@@ -1041,7 +1042,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     unsigned wraw[7][PACKW ? 1 : 2];               // the 14 taps of this lane's A rows (filter rows kh0 / kh1, all column shifts): read once per slab
     auto fetch = [&](const char* in_s, int kw, int slot) {
 #pragma unroll
-        for (int rb = 0; rb < NBF; ++rb) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);
+        for (int rb = 0; rb < NBF; ++rb)
+            if (NP > 1 || rb != 1) bf[slot][rb].u = *reinterpret_cast<const uint4*>(in_s + sw[kw] + 2 * rb * ROWB);      // (one row pair: fragments 0 and 2 only)
     };
     auto taps = [&](const char* in_s) {
 #pragma unroll
@@ -1186,15 +1188,15 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
     half_t* yb = PAIR ? y + ((long)b * 2 * H + h0) * 8 * C : y + (((long)b * H + h0) * W + w0) * C;      // PAIR: b = pair index
     // two halves (TH = 8: row pairs 0-1 / 2-3 = pixels 0-63 / 64-127): the stores of the first leave while the second is normalised
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < NHF; ++hf) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const float4 gw = *reinterpret_cast<const float4*>(par_s + C + s * 64 + cq);
             const float4 gb = *reinterpret_cast<const float4*>(par_s + 2 * C + s * 64 + cq);
             const int chunk = s * 8 + wave;
 #pragma unroll
-            for (int p2 = 0; p2 < NP / 2; ++p2) {
-                const int pp = hf * (NP / 2) + p2;
+            for (int p2 = 0; p2 < PPH; ++p2) {
+                const int pp = hf * PPH + p2;
                 half4 ov;
                 ov[0] = (_Float16)fmaf(fmaf(acc[s][pp][0], rstd[pp], nmr[pp]), gw.x, gb.x);
                 ov[1] = (_Float16)fmaf(fmaf(acc[s][pp][1], rstd[pp], nmr[pp]), gw.y, gb.y);
@@ -1210,8 +1212,8 @@ __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(cons
         asm volatile("" ::: "memory");
         GP_DWT_MARK(43 + 2 * hf);
 #pragma unroll 4
-        for (int i = tid; i < (NPX / 2) * cpp; i += 512) {
-            const int px = hf * (NPX / 2) + i / cpp, c = i % cpp;
+        for (int i = tid; i < (NPX / NHF) * cpp; i += 512) {
+            const int px = hf * (NPX / NHF) + i / cpp, c = i % cpp;
             const uint4 v = *reinterpret_cast<const uint4*>(out_s + px * (C * 2) + ((c ^ (px & 15)) << 4));
             if constexpr (PAIR) *reinterpret_cast<uint4*>(yb + ((long)((px & 15) >> 3) * H * 8 + (px >> 4) * 8 + (px & 7)) * C + c * 8) = v;
             else *reinterpret_cast<uint4*>(yb + ((long)(px >> 4) * W + (px & 15)) * C + c * 8) = v;
@@ -1827,6 +1829,10 @@ static long dw_tallw_min_wgs(int C) {
     static const long k = [] { const char* e = getenv("GP_DW_TALLW_MIN"); return e ? atol(e) : -1l; }();
     return k >= 0 ? k : C == 128 ? 384 : 256;
 }
+static int dw_pair_rows() {   // GP_DW_PAIR_ROWS=4|2: tile height of the pair form (A/B)
+    static const int k = [] { const char* e = getenv("GP_DW_PAIR_ROWS"); return e && atoi(e) == 4 ? 4 : 2; }();
+    return k;
+}
 static long dw_pair_min_crops() {     // the pair-tile form at stage 3 (GP_DW_PAIR_MIN: A/B; a huge value switches it off)
     static const long k = [] { const char* e = getenv("GP_DW_PAIR_MIN"); return e ? atol(e) : 32l; }();
     return k;
@@ -1886,8 +1892,11 @@ extern "C" int gp_dwconv_ln(const void* x, const void* wt, const float* bias, co
     }
     // 8 x 8 maps at C = 1024 (ConvNeXt stage 3): two images per 16-column tile, from dw_pair_min_crops() crops up (even batch); act code 113 forces it
     if (KS == 7 && act == GP_ACT_NONE && n_pixels == total && dtype == GP_F16 && W == 8 && H % 4 == 0 && C == 1024 && B % 2 == 0 && x != y &&
-        (dbg == 13 || (dbg == 0 && B >= dw_pair_min_crops()))) {
-        launch_dw7_tall<16, 8, false, false, 4, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+        (dbg == 13 || dbg == 14 || (dbg == 0 && B >= dw_pair_min_crops()))) {
+        // quarter-image tiles of the pair (TH = 2, the default: 2 B workgroups, two B fragments per two MFMAs: 23.3 -> 18.7 us per 128 crops, 21.8 -> 16.7 per 64; act code 114)
+        // or half-image tiles (TH = 4: act code 113, GP_DW_PAIR_ROWS=4); same bits
+        if (dbg == 14 || (dbg == 0 && dw_pair_rows() == 2)) launch_dw7_tall<16, 8, false, false, 2, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
+        else launch_dw7_tall<16, 8, false, false, 4, true>(x, wt, bias, ln_w, ln_b, y, B, H, W, eps, s);
         GP_LAUNCH_CHECK("gp_dwconv_ln");
     }
     // quarter-image tiles (TH = 4) of 16-wide maps where the half-image tiles would leave the chip half empty (33 .. 64 crops at stage 2); act code 112 forces it

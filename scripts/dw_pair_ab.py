@@ -11,7 +11,7 @@ for B in (128, 96, 64, 48, 32, 24, 16, 8, 4, 2):
     x = torch.randn(B, H, H, C, generator=g).half().cuda()
     w = (torch.randn(49, C, generator=g) / 7).half().cuda()
     b, lw, lb = (torch.randn(C, generator=g).cuda() for _ in range(3))
-    ys = {a: torch.empty_like(x) for a in (107, 113)}
+    ys = {a: torch.empty_like(x) for a in (107, 113, 114)}
     def timed(a, n=40):
         f = lambda: ops.dwconv_ln(x, w, b, lw, lb, ys[a], 7, act=a)
         for _ in range(3): f()
@@ -26,5 +26,5 @@ for B in (128, 96, 64, 48, 32, 24, 16, 8, 4, 2):
         for a in ys: t[a].append(timed(a))
     d = float((ys[107].float() - ys[113].float()).abs().max())
     mb = 2 * x.numel() * 2 / 1e6
-    print(f"C={C} {H}x{H} B={B} ({mb:.1f} MB in + out: {mb / 6.3:.1f} us at 6.3 TB/s): strip kernel {statistics.median(t[107]):.1f} us | pair tiles {statistics.median(t[113]):.1f} us "
+    print(f"C={C} {H}x{H} B={B} ({mb:.1f} MB in + out: {mb / 6.3:.1f} us at 6.3 TB/s): strip kernel {statistics.median(t[107]):.1f} us | pair tiles, 4 rows {statistics.median(t[113]):.1f} us, 2 rows {statistics.median(t[114]):.1f} us "
           f"| max |pair - strip| {d:.2e}", flush=True)

@@ -812,6 +812,10 @@ def test_dwconv_ln_tall_tiles(C, H, B, offset, W):
     o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2, 7, act=force)
     nz = (out != out2).nonzero()
     assert nz.shape[0] == 0, (nz.shape[0], nz[:8].tolist(), float((out.float() - out2.float()).abs().max()), float((out2.float() - ref.cuda()).abs().max()), float((out.float() - ref.cuda()).abs().max()))
+    if W == 8:                        # the pair form on quarter-image tiles (TH = 2; act code 114): same arithmetic per pixel, same bits
+        out2r = torch.zeros_like(out)
+        o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out2r, 7, act=114)
+        assert torch.equal(out, out2r), float((out.float() - out2r.float()).abs().max())
     if W == 16:                       # the quarter-image form (TH = 4; act code 112): what a launch of 33 .. 64 crops at stage 2 takes
         out4 = torch.zeros_like(out)
         o.dwconv_ln(xd, wd, b.cuda(), lw.cuda(), lb.cuda(), out4, 7, act=112)
