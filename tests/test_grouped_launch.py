@@ -206,11 +206,12 @@ def test_single_batch_bs64_second_seed_meets_1e_4(oracle_2x64, mode):
     assert e["rot"] < 1e-4 + noise and e["trans"] < 1e-4 and e["size"] < 1e-4, (e, noise)
 
 
-@pytest.mark.parametrize("seed", [642, 643, 644, 645])
+@pytest.mark.parametrize("seed", [642, 645])
 def test_split_mode_bs64_more_seeds_meet_1e_4_against_float64(seed):
     """Round-4 review: the split-operand mode meets north_star's 1e-4 against the fp32 CPU oracle with 7 % of margin on the bench batch, and
     the asserts above compare with `1e-4 + (fp32 oracle - float64 oracle)` because that oracle's own rounding error on its worst-conditioned
-    crop is of the size of the bar.  Here: four MORE batch seeds at bs = 64 against the oracle run in FLOAT64, the plain < 1e-4 on R / t / s
+    crop is of the size of the bar.  Here: two MORE batch seeds at bs = 64 (four until round 6: 643 and 644 dropped for the suite's time budget, ~37 s of float64
+    oracle each) against the oracle run in FLOAT64, the plain < 1e-4 on R / t / s
     with no noise term -- so that the margin against the fp32 oracle cannot hide a seed at 1.2e-4."""
     from givepose_amd import PoseNet, PoseNetConfig
     cfg = PoseNetConfig()
