@@ -659,6 +659,30 @@ def main():
                     ent["frame_by_frame_crops_per_s"] = round(ntot / sorted(reps1)[1], 1)
                     ent["frame_by_frame_ms_per_frame"] = round(sorted(reps1)[1] / nfr * 1e3, 3)
                 fg[f"{nfr}_frames"] = ent
+            # the same with TWO such launch sequences in flight (two slots of one PoseNet, alternating, wait=False): what a caller that keeps the
+            # detections of the next frames queued gets -- a 24-crop launch sequence alone leaves most of the chip idle
+            net2 = PoseNet(cfg, seed=0, use_graph=not args.no_graph, inflight=2, **mode).to(dev)
+            for nfr in (6, 16):
+                sizes = sizes_all[:nfr]
+                ntot = sum(sizes)
+                cats = []
+                for s_ in range(2):
+                    fr = [{k: torch.from_numpy(v).to(dev) for k, v in synth.synth_batch(b, seed=50 + 40 * s_ + i).items()} for i, b in enumerate(sizes)]
+                    cats.append({k: torch.cat([f[k] for f in fr], 0) for k in fr[0]})
+                for _ in range(4):
+                    for s_ in range(2):
+                        net2.forward_device(cats[s_], dev, slot=s_, wait=False, groups=sizes)
+                torch.cuda.synchronize(dev)
+                reps = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        for s_ in range(2):
+                            net2.forward_device(cats[s_], dev, slot=s_, wait=False, groups=sizes)
+                    torch.cuda.synchronize(dev)
+                    reps.append((time.perf_counter() - t0) / 40)
+                fg[f"{nfr}_frames"]["crops_per_s_two_launch_sequences_in_flight"] = round(ntot / sorted(reps)[1], 1)
+            del net2
             line["frames_grouped"] = dict(fg, unit="crops/s (one rank, one launch sequence at a time, hipGraph replay, inputs resident)",
                                           note="frames of 2-6 detections (mean 4), the detections of N frames per launch sequence with per-frame DCNv3 coupling "
                                                "(gp_dwconv_ln_groups); frame_by_frame = one forward per frame, today's call pattern of evaluation/evaluate.py")
@@ -738,6 +762,7 @@ def main():
             "latency_b1_ms": g("latency_b1", "ms"), "latency_b4_ms": g("latency_b4", "ms"),
             "frames_grouped_crops_per_s_6_16_32_frames": [(g("frames_grouped", f"{n}_frames") or {}).get("crops_per_s") for n in (6, 16, 32)],
             "frame_by_frame_crops_per_s": (g("frames_grouped", "6_frames") or {}).get("frame_by_frame_crops_per_s"),
+            "frames_grouped_two_in_flight_crops_per_s_6_16_frames": [(g("frames_grouped", f"{n}_frames") or {}).get("crops_per_s_two_launch_sequences_in_flight") for n in (6, 16)],
             "cpu_baseline_images_per_s": g("cpu_baseline", "value"),
             "cpu_cores": g("cpu_baseline", "cores")}
         print(json.dumps(line, allow_nan=False), flush=True)

@@ -114,6 +114,30 @@ def test_ragged_equals_single_frame_forwards_and_launch_count_is_flat():
     assert n6 == n2 == n22
 
 
+def test_two_ragged_launch_sequences_in_flight_equal_one_at_a_time():
+    """Two ragged frame sets on two slots of one PoseNet, launched back to back with wait=False (the `frames_grouped` leg's
+    `crops_per_s_two_launch_sequences_in_flight`: each slot owns its buffers, its group table, its hipGraph and its stream): the poses of
+    both are bitwise what the same sets give one at a time (same net, a device synchronise between the launches), replay after replay."""
+    from givepose_amd import PoseNet, PoseNetConfig
+    cfg = PoseNetConfig()
+    sets = [((2, 5, 1, 4), 930), ((3, 3, 6), 940)]             # 12 crops each -> bucket 16 (different group tables, same plan shape)
+    data = [_cat([_batch(b, seed + i) for i, b in enumerate(sizes)]) for sizes, seed in sets]
+    data = [{k: v.cuda() for k, v in d.items()} for d in data]
+    two = PoseNet(cfg, seed=0, use_graph=True, inflight=2, dtype=torch.float16).cuda()
+    alone = []                                                # one at a time on the SAME net (a net built for overlap picks other GEMM schedules than inflight = 1: fp16 roundings)
+    for s_, ((sizes, _), d) in enumerate(zip(sets, data)):
+        for _ in range(3):
+            o = two.forward_device(d, slot=s_, wait=True, groups=sizes)
+            torch.cuda.synchronize()
+        alone.append({k: o[k].clone() for k in ("rot", "trans", "size")})
+    for rep in range(5):                                      # eager, capture, then replays with both sequences in flight
+        outs = [two.forward_device(d, slot=s, wait=False, groups=sizes) for s, ((sizes, _), d) in enumerate(zip(sets, data))]
+        torch.cuda.synchronize()
+        for s in range(2):
+            for k in ("rot", "trans", "size"):
+                assert torch.equal(outs[s][k], alone[s][k]), (rep, s, k)
+
+
 def test_plan_cache_is_bounded():
     """Plans (buffers + hipGraph per crop count) are evicted least-recently-used beyond PoseNet.max_plans; an evicted size still works."""
     from givepose_amd import PoseNet, PoseNetConfig
