@@ -220,7 +220,11 @@ int gp_convnext_stem(const float* img, const float* w, const float* b, const flo
 /* depth-wise KSxKS conv (pad KS/2, stride 1, bias) + LayerNorm over C (+ optional GELU):
  * ConvNeXt block front half (dw7x7 -> LN) and DCNv3's dw_conv branch (dw3x3 -> LN -> GELU,
  * ops_dcnv3/modules/dcnv3.py:277-296).  wt: (KS*KS, C) tap-major, of `dtype`.  Only the first
- * `n_pixels` flat pixels (b,h,w order) are produced (DCNv3 consumes a prefix). */
+ * `n_pixels` flat pixels (b,h,w order) are produced (DCNv3 consumes a prefix).
+ * `act`: a gp_act code.  Codes >= 100 are TEST HOOKS that pin the kernel form the routing would otherwise pick by grid size (the parity tests compare the forms
+ * with each other; results within the tolerances documented there, or the same bits where stated): 104 / 107 LDS-tiled VALU / strip kernel (KS = 7), 110 / 112
+ * the 16 x 8 / 16 x 4 tiles of dwconv7_ln_tall_kernel, 113 / 114 its pair tiles of 4 / 2 rows (C = 1024, 8 x 8 maps), 120 + act / 125 + act the 16 x 4 / 16 x 2
+ * tiles of dwconv3_ln_tile_kernel (KS = 3, C = 256, act = GELU); a forced form on a shape it does not take is GP_ERR_INVALID.  Not part of the stable ABI. */
 int gp_dwconv_ln(const void* x, const void* wt, const float* bias, const float* ln_w, const float* ln_b,
                  void* y, int B, int H, int W, int C, int KS, float eps, int act, long n_pixels, int dtype,
                  void* stream);
