@@ -214,10 +214,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
 // ---------------------------------------------------------------------------- dw3x3 + LN (+GELU), LDS-tiled (round 6)
 // The DCNv3 prefix kernel (ops_dcnv3/modules/dcnv3.py:318-356: x1 = GELU(LN(dw3x3(x))), C = 256) ran on the strip kernel above at 2.7-3.4 x its HBM floor
 // (64 x 64 prefix of 64 crops: 28.9 us for 67 MB, profiles/r06_dw3_forms.txt): every thread fetched its own 3 x 4 input window and its nine taps from L1 / L2,
-// row by row.  Here a workgroup owns 16 x 4 output pixels x all 256 channels: the 18 x 6 halo window (54 KB; out-of-image pixels are zeros) goes through LDS
-// once, a thread (channel octet o = t % 32, pixel slot t / 32: row slot / 2, column half slot % 2) convolves 8 neighbouring pixels of one row from 10 LDS
-// vectors per filter row.  Arithmetic, its order, the two-pass LayerNorm (group_sum over the pixel's 32 lanes) and the GELU are the strip kernel's: same bits.
-// Only whole 4-row blocks of the flat (image, row) list (the prefix of a batch whose crop count is a multiple of 4 is whole images; otherwise the host checks).
+// row by row.  Here a workgroup owns 16 x TH output pixels x all 256 channels: the 18 x (TH + 2) halo window (36 KB at TH = 2, 54 KB at 4; out-of-image pixels are
+// zeros) goes through LDS once, a thread (channel octet o = t % 32, pixel slot t / 32: 16 / PPT slots per tile row) convolves PPT = 2 TH neighbouring pixels of one
+// row from PPT + 2 LDS vectors per filter row.  Arithmetic, its order, the two-pass LayerNorm (group_sum over the pixel's 32 lanes) and the GELU are the strip
+// kernel's: same bits.  Only whole TH-row blocks of the flat (image, row) list (H % TH == 0, so a block never straddles two images; the host checks n_pixels).
 // GELU only (the DCNv3 prefix kernel's activation, compiled in: the strip kernel's per-element `act` switch costs a scalar branch per value -- 2 896 -> 2 210
 // vector instructions per thread; without an activation the compiler contracts the LayerNorm's last multiply-add differently in the two kernels (1 ulp), so
 // that case stays on the strip kernel)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void dwconv3_ln_tile_kernel(const half_t* __re
                                                               const float* __restrict__ lnw, const float* __restrict__ lnb, half_t* __restrict__ y,
                                                               int H, int W, float eps) {
     constexpr int C = 256, HR = TH + 2, HC = 18, PPT = 2 * TH, SPR = 16 / PPT;      // pixels per thread, pixel slots per tile row
-    extern __shared__ __attribute__((aligned(16))) char dw3_lds[];      // [HR][HC][C] halfs = 55 296 bytes
+    extern __shared__ __attribute__((aligned(16))) char dw3_lds[];      // [HR][HC][C] halfs = 36 864 (TH = 2) / 55 296 (TH = 4) bytes
     const int t = threadIdx.x, o = t & 31, slot = t >> 5, r = slot / SPR, ch = slot % SPR;
     const int tpr = W >> 4;
     const int rb = blockIdx.x / tpr, c0 = (blockIdx.x - rb * tpr) * 16;
@@ -859,7 +859,8 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
 // strictly serial bs-64 forward): two row pairs per wave -- the B-fragment sharing is gone (4 fragments for 4 MFMAs per column shift) -- everything else as above.
 // PAIR (8 x 8 maps: ConvNeXt stage 3, C = 1024): TWO images side by side in one 16-column tile -- lane n of a B fragment is column n & 7 of image n >> 3, the pixel
 // slots of a row are [image A: 8][image B: 8][zero][zero] and a column outside its OWN image reads a zero pixel (the same swizzle stays conflict-free:
-// scripts/probes/dw_tall_swizzle.py); TH = 4 (128 accumulator registers at 16 slabs).  The images of a pair are consecutive in memory.
+// scripts/probes/dw_tall_swizzle.py); TH = 4 (128 accumulator registers at 16 slabs) or, the routed form, TH = 2 (one row pair per wave: B fragments 0 and 2 only,
+// one staging half in the epilogue; 2 B workgroups).  The images of a pair are consecutive in memory.
 template <int NS, int J, bool WIDE = false, bool NOMFMA = false, int TH = 8, bool PAIR = false>    // C = 64 NS channels; J LDS-DMA instructions per LOADING wave (waves 0-3) and slab (4 J >= input pieces + 7); NOMFMA: timing ablation (wrong results)
 __global__ __launch_bounds__(512, WIDE ? 2 : 1) void dwconv7_ln_tall_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wt,
                                                                  const float* __restrict__ bias, const float* __restrict__ lnw,
