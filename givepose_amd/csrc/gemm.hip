@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
         eb[i] = eg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         er[i] = half4{0, 0, 0, 0};
         if (et < MT * NT) {
-            const int em = m0 + (et / NT) * 16 + r, en = n0 + (et % NT) * 16 + q * 4;
+            const int em = min(m0 + (et / NT) * 16 + r, p.M - 1), en = n0 + (et % NT) * 16 + q * 4;      // (plain GEMMs: M need not fill the last row tile)
             if (p.bias) eb[i] = *reinterpret_cast<const f32x4*>(p.bias + en);
             if (p.epi == GP_EPI_SCALE_RES) eg[i] = *reinterpret_cast<const f32x4*>(p.gamma + en);
             if (p.epi == GP_EPI_SCALE_RES || p.epi == GP_EPI_RES_RELU) er[i] = load_res4<half_t>(p, em, en);
@@ -1966,7 +1966,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
             xrow[mt] = reinterpret_cast<const half_t*>(p.X) + ((long)b * p.H * p.Win) * p.Cin + ql * 8;
         } else {
             py[mt] = px[mt] = 0;
-            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + (long)m * p.ldx + ql * 8;
+            xrow[mt] = reinterpret_cast<const half_t*>(p.X) + (long)min(m, p.M - 1) * p.ldx + ql * 8;      // rows past M re-read the last row (never stored)
         }
     }
     const int cpt = CONV ? p.Cin >> 5 : 1;      // K steps per filter tap
@@ -2052,7 +2052,7 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const GemmKP p) {
                 gs += (v[0] + v[1]) + (v[2] + v[3]);
                 gq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             }
-            store4<half_t>(p, m0 + (et / NT) * 16 + r, n0 + (et % NT) * 16 + q * 4, v);
+            if (m0 + (et / NT) * 16 + r < p.M) store4<half_t>(p, m0 + (et / NT) * 16 + r, n0 + (et % NT) * 16 + q * 4, v);
         }
     }
     if constexpr (GN) {
@@ -2092,7 +2092,7 @@ static void launch_smallm(const GemmKP& p, hipStream_t s) {
     // (MT <= 2 with fused statistics: 9, two rounds for the heads' 3 x 3 x 256 convs where the 64-row tile takes three of 6)
     constexpr int KMAX = (CONV && GN) ? (MT == 4 ? 6 : 9) : (CONV || MT + NT > 4) ? 9 : 16;
     const int per = (p.K / 32 + 3) / 4, rounds = (per + KMAX - 1) / KMAX, kch = (per + rounds - 1) / rounds;
-    const dim3 grid(p.N / (16 * NT), p.M / (16 * MT));
+    const dim3 grid(p.N / (16 * NT), (p.M + 16 * MT - 1) / (16 * MT));
     constexpr int LDS = 4 * MT * NT * 1024;
 #define GP_SM(KCH)                                                                                                              \
     do {                                                                                                                        \
@@ -2398,7 +2398,7 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
     const bool smallm_ok = d->dtype == GP_F16 && !split && !r32 && !d->c16 && d->epilogue != GP_EPI_LNFOLD_GELU &&
                            (!d->out_f32 || (d->epilogue <= GP_EPI_LRELU && !d->gn_partial && ((size_t)d->C & 15) == 0)) &&      // fp32 out: the activation epilogues (round 5)
                            (!d->gn_partial || (d->M % (d->gn_rows ? d->gn_rows : 64) == 0 && d->epilogue != GP_EPI_SCALE_RES && d->epilogue != GP_EPI_RES_RELU)) &&
-                           d->N % 32 == 0 && d->M % 16 == 0 && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&
+                           d->N % 32 == 0 && (d->M % 16 == 0 || (d->KH == 0 && !d->gn_partial && d->M > 8)) && (d->KH == 0 || d->Cin % 32 == 0) && ((size_t)d->X & 15) == 0 &&      // (plain GEMMs: any M > 8 -- the PnP fc layers have M = the crop count; round 6)
                            ((size_t)d->W & 15) == 0 && ((size_t)d->C & 7) == 0 && (!d->bias || ((size_t)d->bias & 15) == 0) &&
                            (!d->gamma || ((size_t)d->gamma & 15) == 0) && (!d->residual || ((size_t)d->residual & 7) == 0);
     // variant: 4 = 128x128 LDS-DMA (+split-K), 2 = 256x128, 3 = 256x256, 7..13 see below, 0 = pick
@@ -2435,8 +2435,8 @@ extern "C" int gp_gemm(const gp_gemm_desc* d, void* stream) {
         double best = 1e30;
         const int gn_mt = d->gn_partial ? (d->gn_rows ? d->gn_rows / 16 : 4) : 0;      // fused statistics: the caller's chunk rows ARE the tile rows
         for (int mt = gn_mt ? gn_mt : 1; mt <= (gn_mt ? gn_mt : 4); mt *= 2) {
-            if (d->M % (16 * mt)) continue;
-            const double t = smallm_estimate(d->M, d->N, d->K, mt);
+            if (d->M % (16 * mt) && (d->M % 16 == 0 || mt > 2)) continue;      // (a plain GEMM whose M is no multiple of 16 runs 16- / 32-row tiles with a partial last one)
+            const double t = smallm_estimate((d->M + 16 * mt - 1) / (16 * mt) * (16 * mt), d->N, d->K, mt);
             if (t < best) { best = t; sm_mt = mt; }
         }
         const double tile = (d->gn_partial ? 30.0 : 9.0 + d->K / 160.0 < 22.0 ? 9.0 + d->K / 160.0 : 22.0) + smallm_tile_bias();

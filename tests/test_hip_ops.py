@@ -199,6 +199,27 @@ def test_conv_window_wide_tile_bitwise_vs_square_tile():
     assert torch.equal(o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=813), o.conv2d_nhwc(x16, w, 3, 3, 1, 1, variant=913))
 
 
+@pytest.mark.parametrize("M,N,K", [(24, 256, 1024), (9, 64, 512), (40, 2048, 8192), (17, 1024, 256), (31, 96, 832)])
+def test_gemm_small_m_kernel_with_a_partial_last_row_tile(M, N, K):
+    """Round 6: variant 18 on a plain GEMM whose row count is no multiple of 16 -- ConvPnPNet's fc layers have M = the crop count, and a forward over
+    9 .. 15, 17 .. 31 crops (or the 24-crop bucket of a multi-frame launch) went to a 128 x 128 tile kernel at 22 us a launch where this kernel takes 7.
+    Rows past M re-read the last row and are never stored: sentinel rows behind the output stay untouched; forced and automatic route give the same
+    bits; every epilogue of the PnP path."""
+    o = ops()
+    dt = torch.float16
+    x, w, b = q(rnd(M, K, seed=171), dt), q(rnd(N, K, seed=172, scale=K ** -0.5), dt), rnd(N, seed=173)
+    lin = x @ w.t() + b
+    for epi, ref in ((o.EPI_NONE, lin), (o.EPI_LRELU, F.leaky_relu(lin, 0.1)), (o.EPI_GELU, F.gelu(lin))):
+        outs = []
+        for variant in (18, 0):
+            buf = torch.full((M + 32, N), 7.0, dtype=dt, device="cuda")
+            o.gemm(x.to("cuda", dt), w.to("cuda", dt), buf, bias=b.cuda(), epilogue=epi, variant=variant, M=M)
+            assert rel_err(buf[:M], ref) < TOL[dt], (variant, epi, rel_err(buf[:M], ref))
+            assert bool((buf[M:] == 7.0).all()), (variant, epi)
+            outs.append(buf[:M].clone())
+        assert torch.equal(outs[0], outs[1]), epi      # the automatic choice takes the latency kernel for these shapes
+
+
 def test_gemm_small_m_latency_variant():
     """Variant 18 (few rows: the detections of one frame; four waves split K, fragments straight from global memory, fixed-order
     LDS reduction): every epilogue, ld strides, 16- and 32-row tiles, ragged K ranges (K / 32 not a multiple of 4), the conv forms
