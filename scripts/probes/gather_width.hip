@@ -47,6 +47,45 @@ __global__ __launch_bounds__(256) void gather(const char* __restrict__ buf, unsi
     if (acc == 123.456f) out[0] = acc;
 }
 
+// 16 bytes per lane with SHORTER contiguous runs: SEG bytes per gathered segment (64: four lanes per segment, the row-major fragment loads of gemm_smallm_kernel; 32: two lanes)
+template <int SEG>
+__global__ __launch_bounds__(256) void gather_seg(const char* __restrict__ buf, unsigned ws_mask, int iters, float* out) {
+    constexpr int LPS = SEG / 16;
+    const int lane = threadIdx.x & 63, seg = lane / LPS, within = lane % LPS;
+    const unsigned wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    unsigned state = wid * 2654435761u + seg * 40503u + 12345u;
+    float acc = 0.f;
+    for (int i = 0; i < iters; i += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            state = state * 1664525u + 1013904223u;
+            const unsigned off = ((state >> 4) & ws_mask & ~(unsigned)(SEG - 1)) + within * 16;
+            v[u] = *reinterpret_cast<const float4*>(buf + off);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+template <int SEG> int run_seg(const char* buf, size_t ws, float* out, hipStream_t s) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int G = 256 * 8, iters = 512;
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(gather_seg<SEG>, dim3(G), dim3(256), 0, s, buf, (unsigned)(ws - 1), iters, out);
+        CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double instr = (double)G * 4 * iters, bytes = instr * 1024;
+    printf("  16 B per lane, %3d-byte segments (%2d per instruction): %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz)  %5.2f ns per wave-load per CU\n", SEG, 1024 / SEG, best * 1e3, bytes / best / 1e9,
+           bytes / 256 / (best * 1e-3 * 2.4e9), best * 1e6 / (instr / 256));
+    return 0;
+}
+
 // LDS-DMA arm: the same gathered 1 KB per instruction (8 lanes x 16 bytes per 128-byte segment), written straight into LDS (global_load_lds_dwordx4)
 __global__ __launch_bounds__(256) void gather_dma(const char* __restrict__ buf, unsigned ws_mask, int iters, float* out) {
     __shared__ __attribute__((aligned(1024))) char lds[4 * 4 * 1024];          // 4 waves x 4 KB
@@ -112,7 +151,7 @@ int main() {
     hipStream_t s; CK(hipStreamCreate(&s));
     for (size_t ws : {16384ull, 1ull << 20, 512ull << 20}) {
         printf("working set %zu KB\n", ws >> 10);
-        if (run<4>(buf, ws, out, s) || run<8>(buf, ws, out, s) || run<16>(buf, ws, out, s) || run_dma(buf, ws, out, s)) return 1;
+        if (run<4>(buf, ws, out, s) || run<8>(buf, ws, out, s) || run<16>(buf, ws, out, s) || run_dma(buf, ws, out, s) || run_seg<64>(buf, ws, out, s) || run_seg<32>(buf, ws, out, s) || run_seg<256>(buf, ws, out, s)) return 1;
     }
     return 0;
 }
