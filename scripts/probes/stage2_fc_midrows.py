@@ -14,9 +14,14 @@ for crops in (3, 4, 5, 6, 8, 10, 12):
         bias = torch.randn(N, device="cuda")
         kw = dict(epilogue=ops.EPI_GELU) if name == "fc1" else dict(epilogue=ops.EPI_SCALE_RES, gamma=torch.randn(N, device="cuda") * 0.1, residual=out)
         arms = {}
+        res0 = torch.randn(M, N, device="cuda").half()
         for label, extra in (("auto", {}), ("v18/16", dict(variant=218)), ("v18/32", dict(variant=318)), ("v18/64", dict(variant=418)), ("v7", dict(variant=7)), ("v5", dict(variant=5)), ("v2", dict(variant=2)), ("v8", dict(variant=8)), ("v9", dict(variant=9)), ("v11", dict(variant=11)), ("v12", dict(variant=12)), ("v4 K4", dict(variant=4, splitk=4))):
             try:
-                ops.gemm(x, w, out, bias=bias, **kw, **extra); torch.cuda.synchronize(); arms[label] = extra
+                chk = torch.zeros_like(out)
+                kw2 = dict(kw, residual=res0) if name == "fc2" else kw
+                ops.gemm(x, w, chk, bias=bias, **kw2, **extra); torch.cuda.synchronize(); arms[label] = extra
+                if label == "auto": ref = chk.float()
+                else: assert float((chk.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), (label, float((chk.float() - ref).abs().max()), float(ref.abs().max()))
             except (GivePoseHipError, RuntimeError):
                 pass
         t = {a: [] for a in arms}
